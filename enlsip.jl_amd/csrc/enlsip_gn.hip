@@ -1,0 +1,546 @@
+// libenlsip_gn.so — C ABI (include/enlsip_gn.h) over the gfx950 kernels.
+// One handle = one stream + one lazily grown device workspace.  No exceptions cross the ABI.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "gn_context.hpp"
+#include "gn_kernels_caqr.hpp"
+#include "gn_kernels_constraint.hpp"
+#include "gn_kernels_final.hpp"
+#include "gn_kernels_q1.hpp"
+#include "gn_kernels_update_mfma.hpp"
+#include "gn_kernels_misc.hpp"
+
+using namespace gn;
+
+#define GN_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            char buf__[512];                                                           \
+            snprintf(buf__, sizeof buf__, "%s:%d %s -> %s", __FILE__, __LINE__, #call, \
+                     hipGetErrorString(e__));                                          \
+            h->err = buf__;                                                            \
+            return (int)e__ > 0 ? (int)e__ : 999;                                      \
+        }                                                                              \
+    } while (0)
+
+static inline long long rup(long long x, long long a) { return (x + a - 1) / a * a; }
+
+static int grow(enlsip_gn_handle h, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return 0;
+    if (b.p) GN_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    GN_HIP(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan: geometry + workspace carve for (batch, m, n, t)
+// ---------------------------------------------------------------------------------------------
+static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long n, long long t) {
+    Plan& P = h->plan;
+    if (h->have_plan && P.batch == batch && P.m == m && P.n == n && P.t == t) return 0;
+    P = Plan();
+    P.batch = batch; P.m = m; P.n = n; P.t = t;
+    P.kA = (int)std::min(n, t);
+    P.RPL = h->tile_rows / 64;
+    P.F = 2 * P.RPL;
+    P.ldw = (int)rup(std::max<long long>(m, 1), 32);
+    const long long kpmax = std::min(m, n);
+    P.ldr = (int)rup(std::max<long long>(kpmax, 1), 8);
+    P.npan_max = (int)((kpmax + PB - 1) / PB);
+    long long running = 0;
+    P.panels.resize(P.npan_max);
+    for (int k = 0; k < P.npan_max; ++k) {
+        int nb = P.ldw / 32 - k;  // 32-row blocks from row 32k to ldw
+        long long S = 32;
+        int level = 0;
+        while (true) {
+            LevelPlan L;
+            L.level = level;
+            L.nblocks = nb;
+            L.groups = (nb + P.F - 1) / P.F;
+            L.S = S;
+            L.tOff = running;
+            running += L.groups;
+            P.panels[k].levels.push_back(L);
+            if (L.groups <= 1) break;
+            nb = L.groups;
+            S *= P.F;
+            ++level;
+        }
+    }
+    P.nTblocks = std::max<long long>(running, 1);
+    const long long nblkA = std::max<long long>((P.kA + KBLK - 1) / KBLK, 1);
+    auto pad = [](long long x) { return rup(std::max<long long>(x, 1), 32); };  // 256 B granules
+    P.sFA = pad(n * t); P.sTauA = pad(P.kA); P.sJA = pad(t);
+    P.sFL = pad(t * P.kA); P.sTauL = pad(P.kA); P.sJL = pad(P.kA);
+    P.sTA = pad(nblkA * KBLK * KBLK); P.sP1 = pad(t); P.sB = pad(t);
+    P.sW = pad((long long)P.ldw * (n + 1));
+    P.sT = pad(P.nTblocks * PB * PB);
+    P.sRt = pad((long long)P.ldr * (n + 1));
+    P.sTauJ = pad(kpmax); P.sJJ = pad(n); P.sZ = pad(kpmax);
+    P.sVec = pad((long long)P.ldw * 2);
+    const long long per_dbl = P.sFA + P.sTauA + P.sFL + P.sTauL + P.sTA + P.sP1 + P.sB + P.sW + P.sT + P.sRt +
+                              P.sTauJ + P.sZ + P.sVec;
+    const long long per_i64 = P.sJA + P.sJL + P.sJJ;
+    const size_t bytes = (size_t)batch * (per_dbl * 8 + per_i64 * 8) + (size_t)batch * sizeof(ProbState) + 4096;
+    int rc = grow(h, h->ws, bytes);
+    if (rc) return rc;
+    char* p = (char*)h->ws.p;
+    auto carve = [&](long long stride_elems) {
+        char* r = p;
+        p += (size_t)batch * stride_elems * 8;
+        return r;
+    };
+    h->W = (double*)carve(P.sW);
+    h->FA = (double*)carve(P.sFA); h->tauA = (double*)carve(P.sTauA);
+    h->FL = (double*)carve(P.sFL); h->tauL = (double*)carve(P.sTauL);
+    h->TA = (double*)carve(P.sTA); h->p1 = (double*)carve(P.sP1); h->bvec = (double*)carve(P.sB);
+    h->Tbuf = (double*)carve(P.sT); h->Rt = (double*)carve(P.sRt); h->tauJ = (double*)carve(P.sTauJ);
+    h->zsave = (double*)carve(P.sZ); h->vec = (double*)carve(P.sVec);
+    h->jpvtA = (long long*)carve(P.sJA); h->jpvtL = (long long*)carve(P.sJL); h->jpvtJ = (long long*)carve(P.sJJ);
+    h->state = (ProbState*)p;
+    if (h->h_state_cap < (size_t)batch) {
+        if (h->h_state) GN_HIP(hipHostFree(h->h_state));
+        h->h_state = nullptr;
+        GN_HIP(hipHostMalloc((void**)&h->h_state, (size_t)batch * sizeof(ProbState), hipHostMallocDefault));
+        h->h_state_cap = (size_t)batch;
+    }
+    h->have_plan = true;
+    h->factors_valid = false;
+    return 0;
+}
+
+static int check_limits(enlsip_gn_handle h, long long batch, long long m, long long n, long long t) {
+    if (batch < 1) { h->err = "batch must be >= 1"; return -2; }
+    if (m < 1 || m > (1LL << 30)) { h->err = "m out of range"; return -3; }
+    if (n < 1 || n > 1024) { h->err = "n must be in 1..1024 in this build"; return -4; }
+    if (t < 0 || t > 1024) { h->err = "t must be in 0..1024 in this build"; return -5; }
+    return 0;
+}
+
+// kernels that declare more than 64 KB of dynamic LDS need the opt-in attribute
+template <class KernelT>
+static void big_lds(KernelT k, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+#define GN_LAUNCH_BIG(kern, grid, block, lds, stream, args) \
+    do {                                                     \
+        big_lds(kern, lds);                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, args); \
+    } while (0)
+
+// dispatch helpers over the rows-per-lane instantiations of the single-workgroup kernels
+static void launch_constraint(int rows, int batch, hipStream_t s, const ConstraintArgs& a) {
+    const size_t lds = (size_t)CONSTRAINT_LDS_DOUBLES * 8;
+    if (rows <= 64) GN_LAUNCH_BIG((k_constraint<1, 8>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 128) GN_LAUNCH_BIG((k_constraint<2, 8>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 256) GN_LAUNCH_BIG((k_constraint<4, 8>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 512) GN_LAUNCH_BIG((k_constraint<8, 4>), dim3(batch), dim3(1024), lds, s, a);
+    else GN_LAUNCH_BIG((k_constraint<16, 2>), dim3(batch), dim3(1024), lds, s, a);
+}
+static void launch_pivot(int rows, int batch, hipStream_t s, const FinalArgs& a) {
+    const size_t lds = (size_t)FINAL_LDS_DOUBLES * 8;
+    if (rows <= 64) GN_LAUNCH_BIG((k_pivot_solve<1, 8>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 128) GN_LAUNCH_BIG((k_pivot_solve<2, 8>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 256) GN_LAUNCH_BIG((k_pivot_solve<4, 8>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 512) GN_LAUNCH_BIG((k_pivot_solve<8, 4>), dim3(batch), dim3(1024), lds, s, a);
+    else GN_LAUNCH_BIG((k_pivot_solve<16, 2>), dim3(batch), dim3(1024), lds, s, a);
+}
+
+static CaqrArgs caqr_args(enlsip_gn_handle h, int k, const LevelPlan& L) {
+    const Plan& P = h->plan;
+    CaqrArgs a{};
+    a.m = (int)P.m; a.n = (int)P.n; a.ldw = P.ldw;
+    a.panel = k; a.level = L.level; a.F = P.F; a.nblocks = L.nblocks; a.S = L.S; a.tOff = L.tOff;
+    a.W = h->W; a.sW = P.sW; a.Tbuf = h->Tbuf; a.sT = P.sT; a.state = h->state;
+    a.ext_cols = 0; a.C = nullptr; a.sC = 0; a.reverse = 0;
+    return a;
+}
+
+static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
+    dim3 grid(groups, (unsigned)h->plan.batch);
+    if (h->plan.RPL == 8) hipLaunchKernelGGL(k_caqr_factor<8>, grid, dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_caqr_factor<4>, grid, dim3(256), 0, h->stream, a);
+}
+static void launch_update_refl(enlsip_gn_handle h, const CaqrArgs& a, int groups, int ncols) {
+    dim3 grid(groups, (ncols + 31) / 32, (unsigned)h->plan.batch);
+    if (h->plan.RPL == 8) hipLaunchKernelGGL(k_caqr_update_refl<8>, grid, dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_caqr_update_refl<4>, grid, dim3(256), 0, h->stream, a);
+}
+
+// Apply Q0' (reverse = 0) or Q0 (reverse = 1) of the resident CAQR factors to the external
+// matrix C (ldw x ncols per problem).
+static void caqr_apply_ext(enlsip_gn_handle h, double* C, long long sC, int ncols, int npan, bool reverse) {
+    const Plan& P = h->plan;
+    for (int kk = 0; kk < npan; ++kk) {
+        const int k = reverse ? npan - 1 - kk : kk;
+        const auto& lv = P.panels[k].levels;
+        for (size_t li = 0; li < lv.size(); ++li) {
+            const LevelPlan& L = reverse ? lv[lv.size() - 1 - li] : lv[li];
+            CaqrArgs a = caqr_args(h, k, L);
+            a.ext_cols = ncols; a.C = C; a.sC = sC; a.reverse = reverse ? 1 : 0;
+            launch_update_refl(h, a, L.groups, ncols);
+        }
+    }
+}
+
+// the CAQR sweep over [J2 | d]
+static int run_caqr(enlsip_gn_handle h, int n2_launch) {
+    const Plan& P = h->plan;
+    const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
+    const int npan = (kp_launch + PB - 1) / PB;
+    const bool use_mfma = !(h->flags & ENLSIP_GN_UPDATE_REFLECTORS);
+    for (int k = 0; k < npan; ++k) {
+        const int ntrail = n2_launch + 1 - (k + 1) * PB;  // trailing columns incl. the augmented one
+        for (const LevelPlan& L : P.panels[k].levels) {
+            CaqrArgs a = caqr_args(h, k, L);
+            launch_factor(h, a, L.groups);
+            if (ntrail > 0) {
+                const bool lvl0 = (L.level == 0);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->profiling && lvl0) {
+                    if (h->upd_used + 2 > h->upd_ev.size()) {
+                        for (int q = 0; q < 2; ++q) {
+                            hipEvent_t e;
+                            GN_HIP(hipEventCreate(&e));
+                            h->upd_ev.push_back(e);
+                        }
+                    }
+                    e0 = h->upd_ev[h->upd_used++];
+                    e1 = h->upd_ev[h->upd_used++];
+                    GN_HIP(hipEventRecord(e0, h->stream));
+                }
+                if (use_mfma && lvl0) launch_update_mfma(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
+                else launch_update_refl(h, a, L.groups, ntrail);
+                if (e1) {
+                    GN_HIP(hipEventRecord(e1, h->stream));
+                    const double mk = (double)(P.ldw - k * PB);
+                    h->upd_bytes += (double)P.batch * 8.0 * (2.0 * mk * ntrail + mk * PB + PB * PB);
+                }
+            }
+        }
+    }
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// core: device-pointer batched solve
+// ---------------------------------------------------------------------------------------------
+static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long n, long long t,
+                     const double* dJ, long long ldj, long long strideJ, const double* drx,
+                     const double* dAt, long long ldat, long long strideAt, const double* dcx,
+                     double eps_rank, long long dimA_ov, long long dimJ2_ov,
+                     double* dp, double* db, double* dd, enlsip_gn_info* dinfo,
+                     long long* djA, long long* djL, long long* djJ) {
+    int rc = check_limits(h, batch, m, n, t);
+    if (rc) return rc;
+    if (ldj < m) { h->err = "ldj < m"; return -7; }
+    if (t > 0 && ldat < n) { h->err = "ldat < n"; return -11; }
+    GN_HIP(hipSetDevice(h->device));
+    rc = make_plan(h, batch, m, n, t);
+    if (rc) return rc;
+    const Plan& P = h->plan;
+    h->eps_rank = eps_rank;
+    h->factors_valid = false;
+    h->last_J = dJ; h->last_ldj = ldj; h->last_strideJ = strideJ;
+    h->last_rx = drx; h->last_stride_rx = m;
+    h->last_cx = dcx; h->last_stride_cx = t;
+    h->last_At = dAt; h->last_ldat = ldat; h->last_strideAt = strideAt;
+    hipStream_t s = h->stream;
+    if (h->profiling) {
+        if (!h->ev_ready) {
+            for (int i = 0; i < 8; ++i) GN_HIP(hipEventCreate(&h->ev[i]));
+            h->ev_ready = true;
+        }
+        h->upd_used = 0;
+        h->upd_bytes = 0.0;
+    }
+    auto mark = [&](int i) { if (h->profiling) (void)hipEventRecord(h->ev[i], s); };
+
+    mark(0);
+    // 1. constraint stage
+    ConstraintArgs ca{};
+    ca.n = (int)n; ca.t = (int)t; ca.kA = P.kA; ca.m = (int)m; ca.eps_rank = eps_rank;
+    ca.dimA_override = (int)dimA_ov; ca.code_override = 0;
+    ca.At = dAt; ca.ldat = ldat; ca.strideAt = strideAt; ca.cx = dcx; ca.stride_cx = t;
+    ca.FA = h->FA; ca.sFA = P.sFA; ca.tauA = h->tauA; ca.sTauA = P.sTauA; ca.jpvtA = h->jpvtA; ca.sJA = P.sJA;
+    ca.FL = h->FL; ca.sFL = P.sFL; ca.tauL = h->tauL; ca.sTauL = P.sTauL; ca.jpvtL = h->jpvtL; ca.sJL = P.sJL;
+    ca.TA = h->TA; ca.sTA = P.sTA; ca.p1 = h->p1; ca.sP1 = P.sP1; ca.bvec = h->bvec; ca.sB = P.sB;
+    ca.state = h->state;
+    launch_constraint((int)std::max(n, t), (int)batch, s, ca);
+    mark(1);
+
+    int n2_launch = (int)(n - P.kA);  // speculate rankA = min(n, t); verified after the solve
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // 2. JQ1 = J*Q1, d_temp
+        JQ1Args qa{};
+        qa.m = (int)m; qa.n = (int)n; qa.kA = P.kA; qa.ldw = P.ldw;
+        qa.J = dJ; qa.ldj = ldj; qa.strideJ = strideJ; qa.rx = drx; qa.stride_rx = m;
+        qa.FA = h->FA; qa.sFA = P.sFA; qa.TA = h->TA; qa.sTA = P.sTA; qa.p1 = h->p1; qa.sP1 = P.sP1;
+        qa.W = h->W; qa.sW = P.sW; qa.state = h->state;
+        qa.prob0 = 0;
+        launch_jq1(qa, (int)batch, s);
+        mark(2);
+        // 3. CAQR of [J2 | d]
+        rc = run_caqr(h, n2_launch);
+        if (rc) return rc;
+        mark(3);
+        // 4. pivoted QR of R0 + solves + outputs
+        FinalArgs fa{};
+        fa.m = (int)m; fa.n = (int)n; fa.t = (int)t; fa.kA = P.kA; fa.ldw = P.ldw; fa.ldr = P.ldr;
+        fa.eps_rank = eps_rank; fa.dimJ2_override = (int)dimJ2_ov; fa.refactor = 1;
+        fa.W = h->W; fa.sW = P.sW; fa.Rt = h->Rt; fa.sRt = P.sRt; fa.tauJ = h->tauJ; fa.sTauJ = P.sTauJ;
+        fa.jpvtJ = h->jpvtJ; fa.sJJ = P.sJJ; fa.FA = h->FA; fa.sFA = P.sFA; fa.tauA = h->tauA; fa.sTauA = P.sTauA;
+        fa.p1 = h->p1; fa.sP1 = P.sP1; fa.bvec = h->bvec; fa.sB = P.sB; fa.zsave = h->zsave; fa.sZ = P.sZ;
+        fa.p_out = dp; fa.sPo = n; fa.b_out = db; fa.sBo = t; fa.d_out = dd; fa.sDo = m;
+        fa.jA_out = djA; fa.sJAo = t; fa.jpvtA = h->jpvtA; fa.sJA = P.sJA;
+        fa.jL_out = djL; fa.sJLo = P.kA; fa.jpvtL = h->jpvtL; fa.sJL = P.sJL;
+        fa.jJ_out = djJ; fa.sJJo = n;
+        fa.state = h->state;
+        launch_pivot((int)std::min<long long>(m, n), (int)batch, s, fa);
+        mark(4);
+        GN_HIP(hipGetLastError());
+        GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
+        GN_HIP(hipStreamSynchronize(s));
+        int n2max = 0;
+        for (long long k = 0; k < batch; ++k) n2max = std::max(n2max, h->h_state[k].n2);
+        if (n2max <= n2_launch) break;
+        n2_launch = n2max;  // some A was rank deficient: J2 is wider than speculated, redo from J*Q1
+    }
+    if (dinfo) {
+        // info records are produced on the host from the state mirror and copied to the device buffer
+        std::vector<enlsip_gn_info> tmp((size_t)batch);
+        for (long long k = 0; k < batch; ++k) {
+            const ProbState& st = h->h_state[k];
+            tmp[k] = {st.rankA, st.rankJ2, st.code, st.dimA, st.dimJ2, st.status};
+        }
+        GN_HIP(hipMemcpyAsync(dinfo, tmp.data(), tmp.size() * sizeof(enlsip_gn_info), hipMemcpyHostToDevice, s));
+        GN_HIP(hipStreamSynchronize(s));
+    }
+    if (h->profiling) {
+        float ms;
+        const int map[5][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {0, 4}};
+        GN_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stage_ms[ENLSIP_GN_STAGE_CONSTRAINT] = ms;
+        GN_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); h->stage_ms[ENLSIP_GN_STAGE_JQ1] = ms;
+        GN_HIP(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+        float upd = 0.f;
+        for (size_t i = 0; i + 1 < h->upd_used; i += 2) {
+            float u;
+            GN_HIP(hipEventElapsedTime(&u, h->upd_ev[i], h->upd_ev[i + 1]));
+            upd += u;
+        }
+        h->upd_launches = (long long)(h->upd_used / 2);
+        h->upd_avg_ms = h->upd_launches ? upd / (float)h->upd_launches : 0.f;
+        h->stage_ms[ENLSIP_GN_STAGE_UPDATE] = upd;
+        h->stage_ms[ENLSIP_GN_STAGE_PANEL] = ms - upd;
+        GN_HIP(hipEventElapsedTime(&ms, h->ev[3], h->ev[4])); h->stage_ms[ENLSIP_GN_STAGE_PIVOT] = ms;
+        GN_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[4])); h->stage_ms[ENLSIP_GN_STAGE_TOTAL] = ms;
+        (void)map;
+    }
+    h->factors_valid = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int enlsip_gn_version(void) { return 100; }
+
+int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
+    if (!out) return -1;
+    *out = nullptr;
+    enlsip_gn_context* h = new (std::nothrow) enlsip_gn_context();
+    if (!h) return 998;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        delete h;
+        return e != hipSuccess ? (int)e : 100;  // hipErrorNoDevice
+    }
+    int dev = (opts && opts->device >= 0) ? opts->device : -1;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) {
+        delete h;
+        return -2;
+    }
+    h->device = dev;
+    h->flags = opts ? opts->flags : 0;
+    h->tile_rows = (opts && opts->tile_rows == 256) ? 256 : 512;
+    if (opts && opts->panel_width != 0 && opts->panel_width != PB) {
+        delete h;
+        return -2;
+    }
+    e = hipSetDevice(dev);
+    if (e != hipSuccess) {
+        delete h;
+        return (int)e;
+    }
+    if (opts && opts->stream) {
+        h->stream = (hipStream_t)opts->stream;
+        h->own_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete h;
+            return (int)e;
+        }
+        h->own_stream = true;
+    }
+    // single-workgroup kernels use > 64 KB of dynamic LDS
+    *out = h;
+    return 0;
+}
+
+int enlsip_gn_destroy(enlsip_gn_handle h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->ws.p) (void)hipFree(h->ws.p);
+    if (h->in_stage.p) (void)hipFree(h->in_stage.p);
+    if (h->out_stage.p) (void)hipFree(h->out_stage.p);
+    if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->ev_ready)
+        for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->upd_ev) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+const char* enlsip_gn_last_error(enlsip_gn_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int enlsip_gn_synchronize(enlsip_gn_handle h) {
+    if (!h) return -1;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int enlsip_gn_set_profiling(enlsip_gn_handle h, int enable) {
+    if (!h) return -1;
+    h->profiling = enable != 0;
+    return 0;
+}
+
+int enlsip_gn_get_stage_ms(enlsip_gn_handle h, float* ms) {
+    if (!h) return -1;
+    if (!ms) return -2;
+    for (int i = 0; i < ENLSIP_GN_STAGE_COUNT; ++i) ms[i] = h->stage_ms[i];
+    return 0;
+}
+
+int enlsip_gn_get_update_stats(enlsip_gn_handle h, float* avg_ms, int64_t* launches, double* bytes) {
+    if (!h) return -1;
+    if (avg_ms) *avg_ms = h->upd_avg_ms;
+    if (launches) *launches = h->upd_launches;
+    if (bytes) *bytes = h->upd_bytes;
+    return 0;
+}
+
+int enlsip_gn_solve_batched_dev(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t,
+                                const double* dJ, int64_t ldj, int64_t strideJ, const double* drx,
+                                const double* dAt, int64_t ldat, int64_t strideAt, const double* dcx,
+                                double eps_rank, double* dp, double* db, double* dd, enlsip_gn_info* dinfo,
+                                int64_t* djpvtA, int64_t* djpvtL, int64_t* djpvtJ2) {
+    if (!h) return -1;
+    if (!dJ) return -6;
+    if (!drx) return -9;
+    if (t > 0 && (!dAt || !dcx)) return -10;
+    return solve_dev(h, batch, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, -1, -1, dp, db,
+                     dd, dinfo, (long long*)djpvtA, (long long*)djpvtL, (long long*)djpvtJ2);
+}
+
+static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t, const double* J,
+                      int64_t ldj, int64_t strideJ, const double* rx, const double* At, int64_t ldat,
+                      int64_t strideAt, const double* cx, double eps_rank, int64_t dimA_ov, int64_t dimJ2_ov,
+                      double* p, double* b, double* d, enlsip_gn_info* info, int64_t* jA, int64_t* jL, int64_t* jJ) {
+    if (!h) return -1;
+    int rc = check_limits(h, batch, m, n, t);
+    if (rc) return rc;
+    if (!J) return -6;
+    if (ldj < m) return -7;
+    if (!rx) return -9;
+    if (t > 0 && (!At || !cx)) return -10;
+    if (t > 0 && ldat < n) return -11;
+    GN_HIP(hipSetDevice(h->device));
+    const int kA = (int)std::min(n, t);
+    // staging: inputs packed (ld = m / n), outputs packed
+    const size_t inJ = (size_t)batch * m * n, inAt = (size_t)batch * n * t;
+    const size_t in_bytes = (inJ + (size_t)batch * m + inAt + (size_t)batch * t) * 8 + 1024;
+    rc = grow(h, h->in_stage, in_bytes);
+    if (rc) return rc;
+    const size_t out_dbl = (size_t)batch * (n + t + m);
+    const size_t out_i64 = (size_t)batch * (t + kA + n);
+    rc = grow(h, h->out_stage, (out_dbl + out_i64) * 8 + 1024);
+    if (rc) return rc;
+    double* dJ = (double*)h->in_stage.p;
+    double* drx = dJ + inJ;
+    double* dAt = drx + (size_t)batch * m;
+    double* dcx = dAt + inAt;
+    double* dp = (double*)h->out_stage.p;
+    double* db = dp + (size_t)batch * n;
+    double* dd = db + (size_t)batch * t;
+    long long* djA = (long long*)(dd + (size_t)batch * m);
+    long long* djL = djA + (size_t)batch * t;
+    long long* djJ = djL + (size_t)batch * kA;
+    hipStream_t s = h->stream;
+    for (int64_t k = 0; k < batch; ++k) {
+        GN_HIP(hipMemcpy2DAsync(dJ + (size_t)k * m * n, (size_t)m * 8, J + (size_t)k * strideJ, (size_t)ldj * 8,
+                                (size_t)m * 8, (size_t)n, hipMemcpyHostToDevice, s));
+        if (t > 0)
+            GN_HIP(hipMemcpy2DAsync(dAt + (size_t)k * n * t, (size_t)n * 8, At + (size_t)k * strideAt,
+                                    (size_t)ldat * 8, (size_t)n * 8, (size_t)t, hipMemcpyHostToDevice, s));
+    }
+    GN_HIP(hipMemcpyAsync(drx, rx, (size_t)batch * m * 8, hipMemcpyHostToDevice, s));
+    if (t > 0) GN_HIP(hipMemcpyAsync(dcx, cx, (size_t)batch * t * 8, hipMemcpyHostToDevice, s));
+    rc = solve_dev(h, batch, m, n, t, dJ, m, m * n, drx, dAt, n, n * t, dcx, eps_rank, dimA_ov, dimJ2_ov, dp, db, dd,
+                   nullptr, djA, djL, djJ);
+    if (rc) return rc;
+    if (p) GN_HIP(hipMemcpyAsync(p, dp, (size_t)batch * n * 8, hipMemcpyDeviceToHost, s));
+    if (b && t > 0) GN_HIP(hipMemcpyAsync(b, db, (size_t)batch * t * 8, hipMemcpyDeviceToHost, s));
+    if (d) GN_HIP(hipMemcpyAsync(d, dd, (size_t)batch * m * 8, hipMemcpyDeviceToHost, s));
+    if (jA && t > 0) GN_HIP(hipMemcpyAsync(jA, djA, (size_t)batch * t * 8, hipMemcpyDeviceToHost, s));
+    if (jL && kA > 0) GN_HIP(hipMemcpyAsync(jL, djL, (size_t)batch * kA * 8, hipMemcpyDeviceToHost, s));
+    if (jJ) GN_HIP(hipMemcpyAsync(jJ, djJ, (size_t)batch * n * 8, hipMemcpyDeviceToHost, s));
+    GN_HIP(hipStreamSynchronize(s));
+    if (info)
+        for (int64_t k = 0; k < batch; ++k) {
+            const ProbState& st = h->h_state[k];
+            info[k] = {st.rankA, st.rankJ2, st.code, st.dimA, st.dimJ2, st.status};
+        }
+    return 0;
+}
+
+int enlsip_gn_solve_batched(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t, const double* J,
+                            int64_t ldj, int64_t strideJ, const double* rx, const double* At, int64_t ldat,
+                            int64_t strideAt, const double* cx, double eps_rank, double* p, double* b, double* d,
+                            enlsip_gn_info* info, int64_t* jpvtA, int64_t* jpvtL, int64_t* jpvtJ2) {
+    return solve_host(h, batch, m, n, t, J, ldj, strideJ, rx, At, ldat, strideAt, cx, eps_rank, -1, -1, p, b, d,
+                      info, jpvtA, jpvtL, jpvtJ2);
+}
+
+int enlsip_gn_solve(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const double* J, int64_t ldj,
+                    const double* rx, const double* At, int64_t ldat, const double* cx, double eps_rank,
+                    int64_t dimA_override, int64_t dimJ2_override, double* p, double* b, double* d,
+                    enlsip_gn_info* info, int64_t* jpvtA, int64_t* jpvtL, int64_t* jpvtJ2) {
+    return solve_host(h, 1, m, n, t, J, ldj, (int64_t)ldj * n, rx, At, ldat, (int64_t)ldat * t, cx, eps_rank,
+                      dimA_override, dimJ2_override, p, b, d, info, jpvtA, jpvtL, jpvtJ2);
+}
+
+}  // extern "C"
+
+#include "gn_accessors.inc"

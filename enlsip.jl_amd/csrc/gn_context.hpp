@@ -1,0 +1,83 @@
+// Host-side state behind an enlsip_gn_handle: shape plan, device workspace carve, stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/enlsip_gn.h"
+#include "gn_device_utils.hpp"
+
+namespace gn {
+
+struct LevelPlan {
+    int level;
+    int nblocks;      // 32-row blocks entering this level
+    int groups;       // workgroups (= blocks of the next level)
+    long long S;      // block stride (rows)
+    long long tOff;   // first T block index
+};
+struct PanelPlan {
+    std::vector<LevelPlan> levels;
+};
+
+struct Plan {
+    long long batch = 0, m = 0, n = 0, t = 0;
+    int kA = 0;
+    int RPL = 8;         // CAQR rows per lane (tile rows = 64 * RPL)
+    int F = 16;          // blocks per group
+    int ldw = 0, ldr = 0;
+    int npan_max = 0;    // panels if n2 = n
+    long long nTblocks = 0;
+    std::vector<PanelPlan> panels;
+    // per-problem strides (elements)
+    long long sFA, sTauA, sJA, sFL, sTauL, sJL, sTA, sP1, sB, sW, sT, sRt, sTauJ, sJJ, sZ, sVec;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace gn
+
+struct enlsip_gn_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int flags = 0;
+    int tile_rows = 512;
+    std::string err;
+    gn::Plan plan;
+    bool have_plan = false;
+    bool factors_valid = false;
+    double eps_rank = 0.0;
+
+    // workspace (one allocation, carved)
+    gn::DevBuf ws;
+    double *FA = nullptr, *tauA = nullptr, *FL = nullptr, *tauL = nullptr, *TA = nullptr, *p1 = nullptr,
+           *bvec = nullptr, *W = nullptr, *Tbuf = nullptr, *Rt = nullptr, *tauJ = nullptr, *zsave = nullptr,
+           *vec = nullptr;
+    long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
+    gn::ProbState* state = nullptr;
+    // staging for the host-pointer API
+    gn::DevBuf in_stage, out_stage, scratch;
+    gn::ProbState* h_state = nullptr;   // pinned
+    size_t h_state_cap = 0;
+    // device-pointer inputs of the last solve (needed by resolve / get_JQ1 paths)
+    const double* last_J = nullptr; long long last_ldj = 0, last_strideJ = 0;
+    const double* last_rx = nullptr; long long last_stride_rx = 0;
+    const double* last_cx = nullptr; long long last_stride_cx = 0;
+    const double* last_At = nullptr; long long last_ldat = 0, last_strideAt = 0;
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[8] = {};
+    bool ev_ready = false;
+    float stage_ms[ENLSIP_GN_STAGE_COUNT] = {};
+    std::vector<hipEvent_t> upd_ev;   // pairs around level-0 update launches
+    size_t upd_used = 0;
+    double upd_bytes = 0.0;
+    float upd_avg_ms = 0.f;
+    long long upd_launches = 0;
+};

@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's interface for the GN subproblem, over the C ABI.
+
+``GNSolver.solve`` has the argument meaning of the reference's
+``gn_search_direction(J, rx, cx, F_A, F_L11, rankA, t, ε_rank, iter)`` preceded by the QR lines
+of ``update_working_set`` (src/enlsip_functions.jl:206-234, :700, :768-769) and returns the
+quantities those lines write into ``Iteration`` (rankA, rankJ2, dimA, dimJ2, b_gn, d_gn) plus the
+three ``QRPivoted``-like factor views whose accessors (``.R``, ``.p``, ``Qt_mul``, ``Q_mul``) are
+backed by the device-resident factors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+SQRT_EPS = math.sqrt(np.finfo(np.float64).eps)
+
+
+class GNError(RuntimeError):
+    pass
+
+
+def _fptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class GNResult:
+    p: np.ndarray
+    b: np.ndarray
+    d: np.ndarray
+    rankA: int
+    rankJ2: int
+    code: int
+    dimA: int
+    dimJ2: int
+    status: int
+    jpvtA: np.ndarray
+    jpvtL: np.ndarray
+    jpvtJ2: np.ndarray
+
+
+class FactorView:
+    """QRPivoted-like view of one resident factorisation (valid until the next solve)."""
+
+    def __init__(self, solver: "GNSolver", which: int, prob: int = 0):
+        self._s, self._which, self._prob = solver, which, prob
+
+    @property
+    def shape(self):
+        r, c = C.c_int64(), C.c_int64()
+        self._s._chk(self._s._lib.enlsip_gn_factor_shape(self._s._h, self._which, self._prob, C.byref(r), C.byref(c)))
+        return int(r.value), int(c.value)
+
+    @property
+    def R(self) -> np.ndarray:
+        r, c = self.shape
+        out = np.zeros((max(r, 1), c), order="F")
+        self._s._chk(self._s._lib.enlsip_gn_get_R(self._s._h, self._which, self._prob, _fptr(out), max(r, 1)))
+        return out[:r, :]
+
+    def diagR(self) -> np.ndarray:
+        r, c = self.shape
+        out = np.zeros(min(r, c))
+        if out.size:
+            self._s._chk(self._s._lib.enlsip_gn_get_diagR(self._s._h, self._which, self._prob, _fptr(out)))
+        return out
+
+    @property
+    def p(self) -> np.ndarray:
+        _, c = self.shape
+        out = np.zeros(c, dtype=np.int64)
+        if c:
+            self._s._chk(self._s._lib.enlsip_gn_get_jpvt(self._s._h, self._which, self._prob, _fptr(out)))
+        return out
+
+    def Qt_mul(self, v: np.ndarray) -> np.ndarray:
+        out = np.array(v, dtype=np.float64, copy=True)
+        self._s._chk(self._s._lib.enlsip_gn_apply_qt(self._s._h, self._which, self._prob, _fptr(out)))
+        return out
+
+    def Q_mul(self, v: np.ndarray) -> np.ndarray:
+        out = np.array(v, dtype=np.float64, copy=True)
+        self._s._chk(self._s._lib.enlsip_gn_apply_q(self._s._h, self._which, self._prob, _fptr(out)))
+        return out
+
+
+class GNSolver:
+    """One handle = one HIP stream + device workspace (not thread-safe)."""
+
+    def __init__(self, device: int = -1, flags: int = 0, tile_rows: int = 0, stream: int = 0):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        opts = L.Opts(device=device, flags=flags, panel_width=0, tile_rows=tile_rows,
+                      stream=C.c_void_p(stream) if stream else None)
+        rc = self._lib.enlsip_gn_create(C.byref(self._h), C.byref(opts))
+        if rc != 0:
+            raise GNError(f"enlsip_gn_create failed with code {rc} (no usable HIP device?)")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.enlsip_gn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            msg = self._lib.enlsip_gn_last_error(self._h)
+            raise GNError(f"libenlsip_gn error {rc}: {msg.decode() if msg else ''}")
+
+    # ---- single problem, host buffers -------------------------------------------------------
+    def solve(self, J: np.ndarray, rx: np.ndarray, A_active: np.ndarray, cx: np.ndarray,
+              eps_rank: float = SQRT_EPS, dimA: int = -1, dimJ2: int = -1) -> GNResult:
+        """A_active is the t x n active-constraint Jacobian (the reference's ``C.A``)."""
+        J = np.asfortranarray(J, dtype=np.float64)
+        m, n = J.shape
+        A_active = np.asarray(A_active, dtype=np.float64).reshape(-1, n)
+        t = A_active.shape[0]
+        At = np.asfortranarray(A_active.T)                  # n x t column-major
+        rx = np.ascontiguousarray(rx, dtype=np.float64)
+        cx = np.ascontiguousarray(cx, dtype=np.float64)
+        kA = min(n, t)
+        p, b, d = np.zeros(n), np.zeros(t), np.zeros(m)
+        jA, jL, jJ = np.zeros(t, np.int64), np.zeros(kA, np.int64), np.zeros(n, np.int64)
+        info = L.Info()
+        self._chk(self._lib.enlsip_gn_solve(self._h, m, n, t, _fptr(J), m, _fptr(rx), _fptr(At) if t else None,
+                                            max(n, 1), _fptr(cx) if t else None, eps_rank, dimA, dimJ2,
+                                            _fptr(p), _fptr(b), _fptr(d), C.byref(info),
+                                            _fptr(jA), _fptr(jL), _fptr(jJ)))
+        n2 = n - int(info.rankA)
+        return GNResult(p, b, d, int(info.rankA), int(info.rankJ2), int(info.code), int(info.dimA),
+                        int(info.dimJ2), int(info.status), jA, jL, jJ[:n2].copy())
+
+    # ---- batch, host buffers ----------------------------------------------------------------
+    def solve_batched(self, J: np.ndarray, rx: np.ndarray, At: np.ndarray, cx: np.ndarray,
+                      eps_rank: float = SQRT_EPS):
+        """J: (batch, n, m) C-order array holding each m x n problem column-major (i.e. J[k].T is
+        the matrix), rx: (batch, m), At: (batch, t, n) C-order = column-major n x t, cx: (batch, t)."""
+        batch, n, m = J.shape
+        t = At.shape[1] if At is not None and At.size else 0
+        kA = min(n, t)
+        J = np.ascontiguousarray(J, dtype=np.float64)
+        rx = np.ascontiguousarray(rx, dtype=np.float64)
+        p, b, d = np.zeros((batch, n)), np.zeros((batch, t)), np.zeros((batch, m))
+        jA = np.zeros((batch, t), np.int64)
+        jL = np.zeros((batch, kA), np.int64)
+        jJ = np.zeros((batch, n), np.int64)
+        info = (L.Info * batch)()
+        if t:
+            At = np.ascontiguousarray(At, dtype=np.float64)
+            cx = np.ascontiguousarray(cx, dtype=np.float64)
+        self._chk(self._lib.enlsip_gn_solve_batched(
+            self._h, batch, m, n, t, _fptr(J), m, m * n, _fptr(rx), _fptr(At) if t else None, max(n, 1), n * t,
+            _fptr(cx) if t else None, eps_rank, _fptr(p), _fptr(b), _fptr(d),
+            C.cast(info, C.c_void_p), _fptr(jA), _fptr(jL), _fptr(jJ)))
+        infos = [(int(i.rankA), int(i.rankJ2), int(i.code), int(i.dimA), int(i.dimJ2), int(i.status)) for i in info]
+        return p, b, d, infos, jA, jL, jJ
+
+    # ---- batch, device buffers (raw pointers, e.g. torch tensor .data_ptr()) ------------------
+    def solve_batched_dev(self, batch, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx,
+                          eps_rank=SQRT_EPS, dp=0, db=0, dd=0, dinfo=0, djA=0, djL=0, djJ=0):
+        v = lambda x: C.c_void_p(x) if x else None
+        self._chk(self._lib.enlsip_gn_solve_batched_dev(
+            self._h, batch, m, n, t, v(dJ), ldj, strideJ, v(drx), v(dAt), ldat, strideAt, v(dcx), eps_rank,
+            v(dp), v(db), v(dd), v(dinfo), v(djA), v(djL), v(djJ)))
+
+    # ---- resident factors ---------------------------------------------------------------------
+    def factor(self, which: int, prob: int = 0) -> FactorView:
+        return FactorView(self, which, prob)
+
+    def JQ1(self, m: int, n: int, prob: int = 0) -> np.ndarray:
+        out = np.zeros((m, n), order="F")
+        self._chk(self._lib.enlsip_gn_get_JQ1(self._h, prob, _fptr(out), m))
+        return out
+
+    def resolve(self, m: int, n: int, t: int, dimA: int, dimJ2: int, code: int = -1, prob: int = 0):
+        """sub_search_direction re-entry on the resident factors (src/enlsip_functions.jl:1253)."""
+        p, b, d = np.zeros(n), np.zeros(t), np.zeros(m)
+        self._chk(self._lib.enlsip_gn_resolve(self._h, prob, dimA, dimJ2, code, _fptr(p), _fptr(b), _fptr(d)))
+        return p, b, d
+
+    # ---- instrumentation ------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._chk(self._lib.enlsip_gn_set_profiling(self._h, 1 if on else 0))
+
+    def stage_ms(self) -> dict:
+        arr = (C.c_float * len(L.STAGE_NAMES))()
+        self._chk(self._lib.enlsip_gn_get_stage_ms(self._h, arr))
+        return dict(zip(L.STAGE_NAMES, [float(x) for x in arr]))
+
+    def update_stats(self):
+        ms, cnt, by = C.c_float(), C.c_int64(), C.c_double()
+        self._chk(self._lib.enlsip_gn_get_update_stats(self._h, C.byref(ms), C.byref(cnt), C.byref(by)))
+        return float(ms.value), int(cnt.value), float(by.value)
+
+    def synchronize(self):
+        self._chk(self._lib.enlsip_gn_synchronize(self._h))

@@ -1,0 +1,189 @@
+/*
+ * enlsip_gn.h — C ABI of libenlsip_gn.so: the Gauss-Newton search-direction subproblem of
+ * Enlsip.jl as MI355X-native (gfx950) HIP kernels.
+ *
+ * Drop-in boundary.  The reference has no FFI; the seam is two internal Julia
+ * functions, and every entry point below names the reference lines it replaces
+ * (paths relative to the Enlsip.jl repository):
+ *
+ *   enlsip_gn_solve*            gn_search_direction   src/enlsip_functions.jl:206-234
+ *                               sub_search_direction  src/enlsip_functions.jl:116-153
+ *                               + the QR / rank lines of update_working_set
+ *                                                     src/enlsip_functions.jl:700, 768-769
+ *                               pseudo_rank           src/enlsip_functions.jl:17-31
+ *   enlsip_gn_resolve           sub_search_direction re-entry with truncated dimA/dimJ2
+ *                                                     src/enlsip_functions.jl:1249-1253
+ *   enlsip_gn_get_R / _diagR / _jpvt / _apply_qt / _apply_q / _get_JQ1
+ *                               the QRPivoted accessors (.R, .p, .Q', .Q) and J*F_A.Q that
+ *                               first/second_lagrange_mult_estimate!, search_direction_analys,
+ *                               choose_subspace_dimensions, determine_solving_dim consume
+ *                                                     src/enlsip_functions.jl:461-537, 1118-1291
+ *   enlsip_gn_tsqr_*            (new design, no reference counterpart) row-sharded J for
+ *                               multi-GPU TSQR; the exchange itself is done by the caller
+ *                               (RCCL all-gather), see INTEGRATION.md.
+ *
+ * Conventions
+ *   - All matrices column-major (Julia / LAPACK layout), fp64, explicit leading dimensions.
+ *   - Permutations are returned as 1-based LAPACK jpvt (Julia's F.p), int64.
+ *   - Integers that mirror Julia Int / BlasInt are int64_t.
+ *   - Return value: 0 = ok; < 0 = -(index of the offending argument), LAPACK style;
+ *     > 0 = HIP runtime error code (text via enlsip_gn_last_error).  No exceptions cross the ABI.
+ *   - Caller owns every buffer passed in; the library owns device workspaces (grown lazily,
+ *     freed by enlsip_gn_destroy).  One handle = one HIP stream; a handle is not thread-safe,
+ *     distinct handles are independent.
+ *   - "_dev" entry points take DEVICE pointers (hipMalloc memory on the handle's device) and
+ *     leave results in device memory; the others take HOST pointers and stage through PCIe.
+ *   - Factors stay resident on the device behind the handle until the next solve on it.
+ */
+#ifndef ENLSIP_GN_H
+#define ENLSIP_GN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct enlsip_gn_context* enlsip_gn_handle;
+
+/* which factorisation an accessor addresses */
+enum {
+    ENLSIP_GN_FACTOR_A = 0,   /* F_A   = qr(C.A', ColumnNorm())     n  x t   */
+    ENLSIP_GN_FACTOR_L11 = 1, /* F_L11 = qr(F_A.R', ColumnNorm())   t  x kA  */
+    ENLSIP_GN_FACTOR_J2 = 2   /* F_J2  = qr(J2,  ColumnNorm())      m  x n2  */
+};
+
+/* option flags */
+enum {
+    ENLSIP_GN_UPDATE_MFMA = 1,      /* trailing update through v_mfma_f64_16x16x4 (default on)   */
+    ENLSIP_GN_UPDATE_REFLECTORS = 2 /* trailing update by sequential reflectors (debug / A-B)    */
+};
+
+typedef struct enlsip_gn_opts {
+    int32_t device;        /* HIP device ordinal; -1 = current device                          */
+    int32_t flags;         /* 0 = defaults; see enum above                                     */
+    int32_t panel_width;   /* 0 = default (32)                                                 */
+    int32_t tile_rows;     /* 0 = default (512); rows of one CAQR tile, 256 or 512             */
+    void*   stream;        /* hipStream_t to run on, NULL = library creates its own            */
+} enlsip_gn_opts;
+
+/* per-problem scalar results, mirrors Iteration.{rankA,rankJ2,dimA,dimJ2} + code
+ * (src/structures.jl:63-91, src/enlsip_functions.jl:217, 226-229) */
+typedef struct enlsip_gn_info {
+    int64_t rankA;
+    int64_t rankJ2;
+    int64_t code;   /* 1 = rankA == t, -1 = stabilised path */
+    int64_t dimA;
+    int64_t dimJ2;
+    int64_t status; /* 0 ok; bit0: a triangular diagonal was exactly 0 (Julia would throw SingularException) */
+} enlsip_gn_info;
+
+int enlsip_gn_version(void);
+
+int enlsip_gn_create(enlsip_gn_handle* h, const enlsip_gn_opts* opts);
+int enlsip_gn_destroy(enlsip_gn_handle h);
+const char* enlsip_gn_last_error(enlsip_gn_handle h);
+int enlsip_gn_synchronize(enlsip_gn_handle h);
+
+/*
+ * One subproblem, host buffers.  Replaces, for given J (m x n), rx (m), At = C.A' (n x t,
+ * column-major, i.e. the memory of Julia's t x n C.A read row-wise is NOT what is wanted: pass
+ * the transpose explicitly), cx (t):
+ *     F_A = qr(C.A', ColumnNorm()); rankA; F_L11 = qr(F_A.R', ColumnNorm());
+ *     p_gn, F_J2 = gn_search_direction(J, rx, cx, F_A, F_L11, rankA, t, eps_rank, iter)
+ * dimA_override / dimJ2_override: -1 = use rankA / rankJ2 (gn_search_direction);
+ * Outputs: p (n), b (t), d (m), info, jpvtA (t), jpvtL (min(n,t)), jpvtJ2 (n - rankA; buffer of
+ * n entries required).  Any output pointer may be NULL.
+ */
+int enlsip_gn_solve(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t,
+                    const double* J, int64_t ldj, const double* rx,
+                    const double* At, int64_t ldat, const double* cx,
+                    double eps_rank, int64_t dimA_override, int64_t dimJ2_override,
+                    double* p, double* b, double* d, enlsip_gn_info* info,
+                    int64_t* jpvtA, int64_t* jpvtL, int64_t* jpvtJ2);
+
+/*
+ * Batch of independent subproblems of one shape, host buffers.  Problem k uses
+ * J + k*strideJ, rx + k*m, At + k*strideAt, cx + k*t; outputs p + k*n, b + k*t, d + k*m,
+ * info[k], jpvtA + k*t, jpvtL + k*min(n,t), jpvtJ2 + k*n.
+ */
+int enlsip_gn_solve_batched(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t,
+                            const double* J, int64_t ldj, int64_t strideJ, const double* rx,
+                            const double* At, int64_t ldat, int64_t strideAt, const double* cx,
+                            double eps_rank,
+                            double* p, double* b, double* d, enlsip_gn_info* info,
+                            int64_t* jpvtA, int64_t* jpvtL, int64_t* jpvtJ2);
+
+/*
+ * Same, DEVICE buffers in, DEVICE buffers out (inputs are not modified).  Output pointers may be
+ * NULL (results then stay only behind the handle).  The call returns after the work has been
+ * enqueued and the per-problem info has been checked (one stream synchronisation).
+ */
+int enlsip_gn_solve_batched_dev(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t,
+                                const double* dJ, int64_t ldj, int64_t strideJ, const double* drx,
+                                const double* dAt, int64_t ldat, int64_t strideAt, const double* dcx,
+                                double eps_rank,
+                                double* dp, double* db, double* dd, enlsip_gn_info* dinfo,
+                                int64_t* djpvtA, int64_t* djpvtL, int64_t* djpvtJ2);
+
+/* ---- accessors on the resident factors of problem `prob` of the last solve (host buffers) ---- */
+
+/* rows/cols of F.R for `which`: A: min(n,t) x t; L11: min(t,kA) x kA; J2: min(m,n2) x n2 */
+int enlsip_gn_factor_shape(enlsip_gn_handle h, int which, int64_t prob, int64_t* rows, int64_t* cols);
+/* F.R = triu(factors[1:min,:]) into R (ldr >= rows) */
+int enlsip_gn_get_R(enlsip_gn_handle h, int which, int64_t prob, double* R, int64_t ldr);
+int enlsip_gn_get_diagR(enlsip_gn_handle h, int which, int64_t prob, double* diag);
+int enlsip_gn_get_jpvt(enlsip_gn_handle h, int which, int64_t prob, int64_t* jpvt);
+/* v <- F.Q' * v  (length n for A, t for L11, m for J2) */
+int enlsip_gn_apply_qt(enlsip_gn_handle h, int which, int64_t prob, double* v);
+/* v <- F.Q * v */
+int enlsip_gn_apply_q(enlsip_gn_handle h, int which, int64_t prob, double* v);
+/* J * F_A.Q (m x n) into out (ld >= m) — src/enlsip_functions.jl:219, :526, :1249 */
+int enlsip_gn_get_JQ1(enlsip_gn_handle h, int64_t prob, double* out, int64_t ld);
+/*
+ * sub_search_direction(J1, rx, cx, F_A, F_L11, F_J2, n, t, rankA, dimA, dimJ2, code) on the
+ * resident factors (src/enlsip_functions.jl:1253 calls it with code = -1).  code must be 1 or -1.
+ */
+int enlsip_gn_resolve(enlsip_gn_handle h, int64_t prob, int64_t dimA, int64_t dimJ2, int64_t code,
+                      double* p, double* b, double* d);
+
+/* ---- row-sharded TSQR building blocks (multi-GPU config C4) ----------
+ * Local stage on this GPU's row block of [J2 | d_temp] (t = 0: J2 = J, d_temp = -rx):
+ * unpivoted blocked QR, leaves Rloc (n x n upper, packed column-major with ld = n) and
+ * zloc = (Q_loc' d)[1:n] in DEVICE buffers and returns ||(Q_loc' d)[n+1:]||^2 in tail_sq (host).
+ */
+int enlsip_gn_tsqr_local_dev(enlsip_gn_handle h, int64_t m_loc, int64_t n,
+                             const double* dJ, int64_t ldj, const double* drx,
+                             double* dRloc, double* dzloc, double* tail_sq);
+/*
+ * Combine stage, run redundantly on every rank after the all-gather: stacked (G*n) x n matrix of
+ * the G upper-triangular Rloc blocks and the stacked zloc (DEVICE), -> p (n), the leading n
+ * entries of d, rankJ2, jpvtJ2 (HOST outputs).
+ */
+int enlsip_gn_tsqr_combine_dev(enlsip_gn_handle h, int64_t G, int64_t n,
+                               const double* dRstack, const double* dzstack, double eps_rank,
+                               double* p, double* dlead, enlsip_gn_info* info, int64_t* jpvtJ2);
+
+/* ---- instrumentation: HIP-event time (ms) of the stages of the last solve ------------------ */
+enum {
+    ENLSIP_GN_STAGE_CONSTRAINT = 0, /* F_A, F_L11, p1, T factor            */
+    ENLSIP_GN_STAGE_JQ1 = 1,        /* J*Q1 and d_temp                      */
+    ENLSIP_GN_STAGE_PANEL = 2,      /* all CAQR panel factorisations        */
+    ENLSIP_GN_STAGE_UPDATE = 3,     /* all trailing updates                 */
+    ENLSIP_GN_STAGE_PIVOT = 4,      /* pivoted QR of R0 + triangular solves */
+    ENLSIP_GN_STAGE_TOTAL = 5,
+    ENLSIP_GN_STAGE_COUNT = 6
+};
+/* enable = 1 records events per stage (adds stream bubbles; off by default) */
+int enlsip_gn_set_profiling(enlsip_gn_handle h, int enable);
+int enlsip_gn_get_stage_ms(enlsip_gn_handle h, float* ms /* ENLSIP_GN_STAGE_COUNT */);
+/* average duration (ms) and count of the level-0 trailing-update launches of the last solve,
+ * measured with HIP events on the handle's stream (bench.py roofline leg) */
+int enlsip_gn_get_update_stats(enlsip_gn_handle h, float* avg_ms, int64_t* launches,
+                               double* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENLSIP_GN_H */
