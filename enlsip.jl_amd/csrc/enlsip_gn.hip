@@ -201,7 +201,8 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     const int npan = (kp_launch + PB - 1) / PB;
     const bool use_mfma = !(h->flags & ENLSIP_GN_UPDATE_REFLECTORS);
     for (int k = 0; k < npan; ++k) {
-        const int ntrail = n2_launch + 1 - (k + 1) * PB;  // trailing columns incl. the augmented one
+        const int bwk = std::min(PB, kp_launch - k * PB);
+        const int ntrail = n2_launch + 1 - (k * PB + bwk);  // trailing columns incl. the augmented one
         for (const LevelPlan& L : P.panels[k].levels) {
             CaqrArgs a = caqr_args(h, k, L);
             launch_factor(h, a, L.groups);

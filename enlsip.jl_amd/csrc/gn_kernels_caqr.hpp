@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_caqr_update_refl(CaqrArgs a) {
         C = a.C + prob * a.sC;
         ncols = a.ext_cols;
     } else {
-        const int first = r0 + PB;             // J2-local index of the first trailing column
+        const int first = r0 + bw;             // J2-local index of the first trailing column
         ncols = st.n2 + 1 - first;             // includes the augmented column (local index n2)
         C = a.W + prob * a.sW + (size_t)(st.rankA + first) * a.ldw;
     }

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
     const int bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
     const int col0 = st.rankA + r0;
     const int g = blockIdx.x;
-    const int first = r0 + PB;
+    const int first = r0 + bw;
     const int ncols = st.n2 + 1 - first;
     const int cb0 = blockIdx.y * UM_CB;
     if (cb0 >= ncols) return;

@@ -130,6 +130,8 @@ class QRPivoted:
         """``F.Q' * v`` (v has ``rows`` entries; Q behaves as rows x rows)."""
         v = np.asarray(v, dtype=np.float64)
         vec = v.ndim == 1
+        if v.size == 0:
+            return v.copy()
         out = self._ormqr("L", "T", v.reshape(self.rows, -1))
         return out[:, 0].copy() if vec else out
 
@@ -137,6 +139,8 @@ class QRPivoted:
         """``F.Q * v``."""
         v = np.asarray(v, dtype=np.float64)
         vec = v.ndim == 1
+        if v.size == 0:
+            return v.copy()
         out = self._ormqr("L", "N", v.reshape(self.rows, -1))
         return out[:, 0].copy() if vec else out
 

@@ -1,0 +1,52 @@
+"""CPU checks of the drop-in boundary: the library builds for gfx950, loads, and exports every
+symbol include/enlsip_gn.h declares; without a GPU it fails loudly instead of falling back."""
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    import enlsip_gn._lib as L
+    return L.load()
+
+
+def test_header_symbols_exported(lib):
+    import enlsip_gn._lib as L
+    hdr = (ROOT / "include" / "enlsip_gn.h").read_text()
+    declared = set(re.findall(r"\b(enlsip_gn_[a-z_A-Z0-9]+)\s*\(", hdr))
+    declared -= {"enlsip_gn_context"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(L.PROTOTYPES), (declared ^ set(L.PROTOTYPES))
+    assert lib.enlsip_gn_version() >= 100
+
+
+def test_header_cites_reference_lines():
+    hdr = (ROOT / "include" / "enlsip_gn.h").read_text()
+    for cite in ("src/enlsip_functions.jl:206-234", "src/enlsip_functions.jl:116-153",
+                 "src/enlsip_functions.jl:17-31", "src/enlsip_functions.jl:1249-1253"):
+        assert cite in hdr
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from enlsip_gn import GNSolver, GNError
+    with pytest.raises(GNError):
+        GNSolver()
+
+
+def test_product_does_not_import_oracle():
+    for py in (ROOT / "enlsip.jl_amd").rglob("*.py"):
+        txt = py.read_text()
+        assert "oracle" not in txt.replace("CPU oracle under /oracle is test infrastructure only", ""), py
+    for src in (ROOT / "enlsip.jl_amd" / "csrc").iterdir():
+        assert "oracle/" not in src.read_text().replace("oracle/lapack_semantics.py", ""), src
