@@ -13,8 +13,11 @@
 #include "gn_kernels_constraint.hpp"
 #include "gn_kernels_final.hpp"
 #include "gn_kernels_q1.hpp"
+#include "gn_kernels_q1_mfma.hpp"
 #include "gn_kernels_update_mfma.hpp"
 #include "gn_kernels_misc.hpp"
+#include "gn_kernels_qrcp_dist.hpp"
+#include "gn_kernels_qrcp_persist.hpp"
 
 using namespace gn;
 
@@ -89,10 +92,16 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     P.sRt = pad((long long)P.ldr * (n + 1));
     P.sTauJ = pad(kpmax); P.sJJ = pad(n); P.sZ = pad(kpmax);
     P.sVec = pad((long long)P.ldw * 2);
+    P.sM = pad((long long)P.ldr * (n + 1)); P.sVb = pad((long long)P.ldr * std::max<long long>(kpmax, 1));
+    P.sDiag = pad(kpmax); P.sVn = pad(n); P.sQI = pad(n);
+    P.qdGmax = (int)((n + 1 + QD_CPW - 1) / QD_CPW);
+    P.sCand = 2 * (long long)P.qdGmax;
     const long long per_dbl = P.sFA + P.sTauA + P.sFL + P.sTauL + P.sTA + P.sP1 + P.sB + P.sW + P.sT + P.sRt +
-                              P.sTauJ + P.sZ + P.sVec;
+                              P.sTauJ + P.sZ + P.sVec + P.sM + P.sVb + P.sDiag + 2 * P.sVn;
     const long long per_i64 = P.sJA + P.sJL + P.sJJ;
-    const size_t bytes = (size_t)batch * (per_dbl * 8 + per_i64 * 8) + (size_t)batch * sizeof(ProbState) + 4096;
+    const long long per_i32 = 5 * P.sQI;   // chosen + 2 x pos + 2 x colat
+    const size_t bytes = (size_t)batch * (per_dbl * 8 + per_i64 * 8 + per_i32 * 4 + P.sCand * sizeof(QdCand)) +
+                         (size_t)batch * sizeof(ProbState) + 8192;
     int rc = grow(h, h->ws, bytes);
     if (rc) return rc;
     char* p = (char*)h->ws.p;
@@ -107,8 +116,16 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     h->TA = (double*)carve(P.sTA); h->p1 = (double*)carve(P.sP1); h->bvec = (double*)carve(P.sB);
     h->Tbuf = (double*)carve(P.sT); h->Rt = (double*)carve(P.sRt); h->tauJ = (double*)carve(P.sTauJ);
     h->zsave = (double*)carve(P.sZ); h->vec = (double*)carve(P.sVec);
+    h->qdM = (double*)carve(P.sM); h->qdVb = (double*)carve(P.sVb); h->qdDiag = (double*)carve(P.sDiag);
+    h->qdVn1 = (double*)carve(P.sVn); h->qdVn2 = (double*)carve(P.sVn);
     h->jpvtA = (long long*)carve(P.sJA); h->jpvtL = (long long*)carve(P.sJL); h->jpvtJ = (long long*)carve(P.sJJ);
+    h->qdChosen = (int*)p; p += (size_t)batch * P.sQI * 4;
+    h->qdPos = (int*)p; p += (size_t)batch * 2 * P.sQI * 4;
+    h->qdColat = (int*)p; p += (size_t)batch * 2 * P.sQI * 4;
+    h->qdCand = (void*)p; p += (size_t)batch * P.sCand * sizeof(QdCand);
     h->state = (ProbState*)p;
+    p += (((size_t)batch * sizeof(ProbState) + 255) / 256) * 256;
+    h->abort_word = (unsigned*)p;
     if (h->h_state_cap < (size_t)batch) {
         if (h->h_state) GN_HIP(hipHostFree(h->h_state));
         h->h_state = nullptr;
@@ -235,6 +252,69 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     return 0;
 }
 
+// distributed column-pivoted QR of R0 (one launch per pivot step over all problems)
+static int run_qrcp_dist(enlsip_gn_handle h, int n2_launch) {
+    const Plan& P = h->plan;
+    const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
+    QdArgs a{};
+    a.n = (int)P.n; a.ldw = P.ldw; a.ldr = P.ldr; a.step = 0; a.prob0 = 0;
+    a.W = h->W; a.sW = P.sW; a.M = h->qdM; a.sM = P.sM; a.Vb = h->qdVb; a.sVb = P.sVb; a.Rt = h->Rt; a.sRt = P.sRt;
+    a.tau = h->tauJ; a.sTau = P.sTauJ; a.diag = h->qdDiag; a.sDiag = P.sDiag;
+    a.vn1 = h->qdVn1; a.vn2 = h->qdVn2; a.sVn = P.sVn;
+    a.chosen = h->qdChosen; a.pos = h->qdPos; a.colat = h->qdColat; a.sI = P.sQI;
+    a.cand = (QdCand*)h->qdCand; a.sCand = P.sCand; a.Gmax = P.qdGmax;
+    a.jpvt = h->jpvtJ; a.sJ = P.sJJ; a.state = h->state;
+    const int G = (n2_launch + 1 + QD_CPW - 1) / QD_CPW;
+    dim3 grid(G, (unsigned)P.batch);
+    const bool big = kp_launch > 512;
+    if (big) hipLaunchKernelGGL(k_qd_init<16>, grid, dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, h->stream, a);
+    for (int j = 0; j < kp_launch; ++j) {
+        a.step = j;
+        if (big) hipLaunchKernelGGL(k_qd_step<16>, grid, dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL(k_qd_step<8>, grid, dim3(256), 0, h->stream, a);
+    }
+    hipLaunchKernelGGL(k_qd_assemble, grid, dim3(256), 0, h->stream, a);
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+
+// persistent LDS-resident pivoted QR of R0: G co-resident workgroups per problem, chunks of problems
+static int run_qrcp_persist(enlsip_gn_handle h, int n2_launch) {
+    const Plan& P = h->plan;
+    const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
+    const int ctot = n2_launch + 1;
+    const int kp_pad = (kp_launch + 1) & ~1;
+    const size_t slab_budget = 120 * 1024;
+    int cw_max = (int)(slab_budget / ((size_t)kp_pad * 8));
+    cw_max &= ~1;
+    if (cw_max < 2) return -1;
+    int G = (ctot + cw_max - 1) / cw_max;
+    int CW = (ctot + G - 1) / G;
+    CW = (CW + 1) & ~1;
+    if (G > 64 || 2 * G > (int)P.n + 1 || G > P.qdGmax) return -1;   // header poll uses one wave; xbuf reuses qdM
+    const size_t lds = ((size_t)CW * kp_pad + 2 * CW) * 8 + ((size_t)CW + 8) * 4 + 16;
+    const int per_launch = std::max(1, h->cu_count / G);
+    QpArgs a{};
+    a.n = (int)P.n; a.ldw = P.ldw; a.ldr = P.ldr; a.G = G; a.CW = CW; a.kp_pad = kp_pad;
+    a.W = h->W; a.sW = P.sW; a.Rt = h->Rt; a.sRt = P.sRt; a.tau = h->tauJ; a.sTau = P.sTauJ;
+    a.jpvt = h->jpvtJ; a.sJ = P.sJJ; a.hdr = (QpHeader*)h->qdCand; a.sHdr = P.sCand;
+    a.xbuf = h->qdM; a.sX = P.sM; a.abort_word = h->abort_word; a.state = h->state; a.spin_limit = 1 << 20;
+    GN_HIP(hipMemsetAsync(h->qdCand, 0, (size_t)P.batch * P.sCand * sizeof(QpHeader), h->stream));
+    GN_HIP(hipMemsetAsync(h->abort_word, 0, 16, h->stream));
+    const bool big = kp_launch > 512;
+    if (big) big_lds(k_qrcp_persist<16>, lds); else big_lds(k_qrcp_persist<8>, lds);
+    for (int p0 = 0; p0 < (int)P.batch; p0 += per_launch) {
+        const int np = std::min(per_launch, (int)P.batch - p0);
+        a.prob0 = p0;
+        dim3 grid(G, np);
+        if (big) hipLaunchKernelGGL(k_qrcp_persist<16>, grid, dim3(256), lds, h->stream, a);
+        else hipLaunchKernelGGL(k_qrcp_persist<8>, grid, dim3(256), lds, h->stream, a);
+    }
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // core: device-pointer batched solve
 // ---------------------------------------------------------------------------------------------
@@ -291,7 +371,8 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         qa.FA = h->FA; qa.sFA = P.sFA; qa.TA = h->TA; qa.sTA = P.sTA; qa.p1 = h->p1; qa.sP1 = P.sP1;
         qa.W = h->W; qa.sW = P.sW; qa.state = h->state;
         qa.prob0 = 0;
-        launch_jq1(qa, (int)batch, s);
+        if (h->flags & ENLSIP_GN_UPDATE_REFLECTORS) launch_jq1(qa, (int)batch, s);   // plain-FMA A/B partner
+        else launch_jq1_mfma(qa, (int)batch, s);
         mark(2);
         // 3. CAQR of [J2 | d]
         rc = run_caqr(h, n2_launch);
@@ -309,13 +390,34 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         fa.jL_out = djL; fa.sJLo = P.kA; fa.jpvtL = h->jpvtL; fa.sJL = P.sJL;
         fa.jJ_out = djJ; fa.sJJo = n;
         fa.state = h->state;
+        {
+            const int kp_launch = (int)std::min<long long>(m, n2_launch);
+            if ((size_t)kp_launch * (n2_launch + 1) > (size_t)CMAT_DOUBLES) {
+                rc = (h->qrcp_mode == 0) ? run_qrcp_persist(h, n2_launch) : -1;
+                if (rc > 0) return rc;
+                if (rc < 0) {   // shape not supported by the persistent kernel (or it is disabled)
+                    rc = run_qrcp_dist(h, n2_launch);
+                    if (rc) return rc;
+                }
+                fa.refactor = 2;
+            }
+        }
         launch_pivot((int)std::min<long long>(m, n), (int)batch, s, fa);
         mark(4);
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
         GN_HIP(hipStreamSynchronize(s));
         int n2max = 0;
-        for (long long k = 0; k < batch; ++k) n2max = std::max(n2max, h->h_state[k].n2);
+        bool aborted = false;
+        for (long long k = 0; k < batch; ++k) {
+            n2max = std::max(n2max, h->h_state[k].n2);
+            aborted = aborted || (h->h_state[k].status & 4);
+        }
+        if (aborted && h->qrcp_mode == 0) {   // co-residency was not granted in time: use the launch-per-step form
+            h->qrcp_mode = 1;
+            --attempt;
+            continue;
+        }
         if (n2max <= n2_launch) break;
         n2_launch = n2max;  // some A was rank deficient: J2 is wider than speculated, redo from J*Q1
     }
@@ -382,6 +484,15 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
     h->device = dev;
     h->flags = opts ? opts->flags : 0;
     h->tile_rows = (opts && opts->tile_rows == 256) ? 256 : 512;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            h->cu_count = prop.multiProcessorCount;
+        const char* qm = getenv("ENLSIP_GN_QRCP");
+        // ENLSIP_GN_QRCP=persist selects the co-resident LDS kernel; default: one launch per pivot step
+        // (measured faster on MI355X for both batch = 1 and batch = 32, profiles/r1_notes.md)
+        h->qrcp_mode = (qm && qm[0] == 'p') ? 0 : 1;
+    }
     if (opts && opts->panel_width != 0 && opts->panel_width != PB) {
         delete h;
         return -2;

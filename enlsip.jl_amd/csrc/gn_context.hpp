@@ -32,6 +32,9 @@ struct Plan {
     std::vector<PanelPlan> panels;
     // per-problem strides (elements)
     long long sFA, sTauA, sJA, sFL, sTauL, sJL, sTA, sP1, sB, sW, sT, sRt, sTauJ, sJJ, sZ, sVec;
+    // distributed pivoted QR (gn_kernels_qrcp_dist.hpp)
+    long long sM, sVb, sDiag, sVn, sQI, sCand;
+    int qdGmax = 0;
 };
 
 struct DevBuf {
@@ -57,7 +60,12 @@ struct enlsip_gn_context {
     gn::DevBuf ws;
     double *FA = nullptr, *tauA = nullptr, *FL = nullptr, *tauL = nullptr, *TA = nullptr, *p1 = nullptr,
            *bvec = nullptr, *W = nullptr, *Tbuf = nullptr, *Rt = nullptr, *tauJ = nullptr, *zsave = nullptr,
-           *vec = nullptr;
+           *vec = nullptr, *qdM = nullptr, *qdVb = nullptr, *qdDiag = nullptr, *qdVn1 = nullptr, *qdVn2 = nullptr;
+    int *qdChosen = nullptr, *qdPos = nullptr, *qdColat = nullptr;
+    void* qdCand = nullptr;
+    unsigned* abort_word = nullptr;
+    int cu_count = 256;
+    int qrcp_mode = 0;   // 0 persistent (LDS-resident, co-resident workgroups), 1 one launch per pivot step
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
     gn::ProbState* state = nullptr;
     // staging for the host-pointer API

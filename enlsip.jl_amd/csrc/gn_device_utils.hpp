@@ -23,15 +23,37 @@ struct ProbState {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-// butterfly all-reduce: every lane ends with the same bits (same association order in all lanes)
-__device__ __forceinline__ double wave_allsum(double x) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, WAVE);
-    return x;
+// one DPP lane permutation of a double (two 32-bit v_mov_dpp)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
 }
 
+// Wave all-reduce on the DPP crossbar instead of ds_bpermute (no LDS-latency chain): four
+// butterfly steps inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror), then the four row sums are read to SGPRs and added in a fixed order, so every
+// lane ends with the same bits.
+__device__ __forceinline__ double wave_allsum(double x) {
+    x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_f64<0x141>(x);   // row_half_mirror
+    x += dpp_f64<0x140>(x);   // row_mirror
+    const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16);
+    const double r2 = readlane_f64(x, 32), r3 = readlane_f64(x, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+
+// src_lane must be wave-uniform (it is a loop counter everywhere it is used): v_readlane
 __device__ __forceinline__ double wave_bcast(double x, int src_lane) {
-    return __shfl(x, src_lane, WAVE);
+    return readlane_f64(x, src_lane);
 }
 
 // LAPACK dlarfg without the safmin rescaling loop:

@@ -17,7 +17,8 @@ struct FinalArgs {
     int m, n, t, kA, ldw, ldr;
     double eps_rank;
     int dimJ2_override;   // -1 = rankJ2
-    int refactor;         // 1: extract R0 and factor it; 0: reuse resident Rt (resolve path)
+    int refactor;         // 1: extract R0 and factor it here; 2: Rt already factored (distributed path);
+                          // 0: reuse resident Rt (resolve path)
     int prob0;            // problem index offset
     const double* dsrc;   // refactor == 0: transformed right-hand side Q3'd (length m, one problem)
     const double* W;   long long sW;      // ldw x (n+1): R0 in the upper triangle of the J2 columns, d in column n
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(1024) void k_pivot_solve(FinalArgs a) {
 
     if (tid == 0) sh_i[2] = 0;
     int rankJ2 = stp->rankJ2;
-    if (a.refactor) {
+    if (a.refactor == 1) {
         const bool lds = (size_t)kp * (n2 + 1) <= (size_t)CMAT_DOUBLES;
         double* WR = lds ? mat : Rt;
         const int ldx = lds ? kp : ldr;
@@ -91,6 +92,14 @@ __global__ __launch_bounds__(1024) void k_pivot_solve(FinalArgs a) {
                 Rt[i + (size_t)c * ldr] = mat[e];
             }
         }
+        __syncthreads();
+        if (tid == 0) {
+            sh_i[1] = pseudo_rank_serial(kp, a.eps_rank, [&](int i) { return Rt[i + (size_t)i * ldr]; });
+        }
+        __syncthreads();
+        rankJ2 = sh_i[1];
+    } else if (a.refactor == 2) {
+        // factors were produced by the distributed pivoted QR (gn_kernels_qrcp_dist.hpp)
         __syncthreads();
         if (tid == 0) {
             sh_i[1] = pseudo_rank_serial(kp, a.eps_rank, [&](int i) { return Rt[i + (size_t)i * ldr]; });

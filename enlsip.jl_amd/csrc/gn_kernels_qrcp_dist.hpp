@@ -1,0 +1,329 @@
+// Column-pivoted QR (dgeqp3 semantics) of the kp x n2 factor R0 when it is too large for one
+// workgroup's LDS: the columns are distributed over G workgroups (QD_CPW physical columns each)
+// and every pivot step is one launch over (G, batch).  Nothing is ever swapped physically:
+//   * a column keeps its physical slot in M; its logical LAPACK position is tracked in pos[] /
+//     colat[] (double-buffered by step parity, so a step only reads what the previous launch wrote);
+//   * the reflector of step j is written to Vb[:, j] (position-indexed), never into M, so every
+//     workgroup can read the pivot column while its owner retires it;
+//   * each workgroup publishes its best remaining column (max partial norm, ties -> lowest
+//     position = LAPACK's idamax rule) and the next launch reduces the G candidates redundantly.
+// k_qd_assemble finally gathers Rt = [R above / beta on / V below the diagonal] in pivoted order.
+// Norm downdate, recompute rule and reflector generation are those of oracle/lapack_semantics.py.
+#pragma once
+#include "gn_device_utils.hpp"
+
+namespace gn {
+
+constexpr int QD_CPW = 8;   // physical columns per workgroup (2 per wave)
+
+struct QdCand {
+    double val;
+    int pos;
+    int col;
+};
+
+struct QdArgs {
+    int n, ldw, ldr, step;
+    int prob0;
+    const double* W;  long long sW;      // CAQR result: R0 in the upper triangle of the J2 columns, d in column n
+    double* M;        long long sM;      // ldr x (n + 1) physical columns (+ rhs at index n2)
+    double* Vb;       long long sVb;     // ldr x kpmax reflectors by position
+    double* Rt;       long long sRt;     // ldr x (n + 1) assembled factors
+    double* tau;      long long sTau;
+    double* diag;     long long sDiag;
+    double* vn1;      long long sVn;     // n each
+    double* vn2;
+    int* chosen;      long long sI;      // n
+    int* pos;                            // 2 x n   (parity-major)
+    int* colat;                          // 2 x n
+    QdCand* cand;     long long sCand;   // 2 x Gmax
+    int Gmax;
+    long long* jpvt;  long long sJ;
+    const ProbState* state;
+};
+
+__device__ __forceinline__ bool qd_better(double v, int p, double bv, int bp) {
+    return v > bv || (v == bv && p < bp);
+}
+
+// extract own columns, initial norms / permutation / candidate
+template <int RPL>
+__global__ __launch_bounds__(256) void k_qd_init(QdArgs a) {
+    __shared__ double cval[QD_CPW];
+    __shared__ int cpos[QD_CPW];
+    const int prob = blockIdx.y + a.prob0;
+    const ProbState st = a.state[prob];
+    const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
+    const int g = blockIdx.x;
+    if (kp == 0 || g * QD_CPW >= ctot) return;
+    const int ln = lane_id(), w = wave_id();
+    const double* W = a.W + prob * a.sW;
+    double* M = a.M + prob * a.sM;
+    for (int u = 0; u < 2; ++u) {
+        const int slot = 2 * w + u;
+        const int c = g * QD_CPW + slot;
+        double s = 0.0;
+        if (c < ctot) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const int r = ln + 64 * i;
+                if (r < kp) {
+                    double v;
+                    if (c < n2) v = (r <= c) ? W[r + (size_t)(st.rankA + c) * a.ldw] : 0.0;
+                    else v = W[r + (size_t)a.n * a.ldw];
+                    M[r + (size_t)c * a.ldr] = v;
+                    s += v * v;
+                }
+            }
+        }
+        s = wave_allsum(s);
+        if (ln == 0) {
+            if (c < n2) {
+                const double nv = sqrt(s);
+                a.vn1[prob * a.sVn + c] = nv;
+                a.vn2[prob * a.sVn + c] = nv;
+                a.chosen[prob * a.sI + c] = -1;
+                a.pos[prob * 2 * a.sI + c] = c;
+                a.colat[prob * 2 * a.sI + c] = c;
+                cval[slot] = nv;
+                cpos[slot] = c;
+            } else {
+                cval[slot] = -1.0;
+                cpos[slot] = 0x7fffffff;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bv = -1.0;
+        int bp = 0x7fffffff, bc = -1;
+        for (int s = 0; s < QD_CPW; ++s)
+            if (qd_better(cval[s], cpos[s], bv, bp)) {
+                bv = cval[s];
+                bp = cpos[s];
+                bc = g * QD_CPW + s;
+            }
+        QdCand cd = {bv, bp, bc};
+        a.cand[prob * a.sCand + g] = cd;   // parity 0
+    }
+}
+
+template <int RPL>
+__global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
+    __shared__ double cval[QD_CPW];
+    __shared__ int cpos[QD_CPW];
+    const int prob = blockIdx.y + a.prob0;
+    const ProbState st = a.state[prob];
+    const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
+    const int j = a.step;
+    const int g = blockIdx.x;
+    if (j >= kp || g * QD_CPW >= ctot) return;
+    const int gact = (ctot + QD_CPW - 1) / QD_CPW;
+    const int ln = lane_id(), w = wave_id();
+    const int par = j & 1;
+    double* M = a.M + prob * a.sM;
+    double* vn1 = a.vn1 + prob * a.sVn;
+    double* vn2 = a.vn2 + prob * a.sVn;
+    int* chosen = a.chosen + prob * a.sI;
+    const int* pos_old = a.pos + prob * 2 * a.sI + par * a.sI;
+    int* pos_new = a.pos + prob * 2 * a.sI + (par ^ 1) * a.sI;
+    const int* colat_old = a.colat + prob * 2 * a.sI + par * a.sI;
+    int* colat_new = a.colat + prob * 2 * a.sI + (par ^ 1) * a.sI;
+    const QdCand* cand_old = a.cand + prob * a.sCand + par * a.Gmax;
+    QdCand* cand_new = a.cand + prob * a.sCand + (par ^ 1) * a.Gmax;
+    const double tol3z = 1.4901161193847656e-08;
+
+    // Everything that does not depend on the pivot is requested first, so the step costs two
+    // dependent memory round trips (candidates -> pivot column) instead of four.
+    const int cbase = g * QD_CPW + 2 * w;
+    int cst[2], cps[2];
+    double cv1[2], cv2[2];
+    double x[2][RPL];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = cbase + u;
+        const bool real = c < n2;
+        cst[u] = real ? chosen[c] : -1;
+        cps[u] = real ? pos_old[c] : 0x7fffffff;
+        cv1[u] = real ? vn1[c] : 0.0;
+        cv2[u] = real ? vn2[c] : 1.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = j + ln + 64 * i;
+            x[u][i] = (c < ctot && r < kp) ? M[r + (size_t)c * a.ldr] : 0.0;
+        }
+    }
+    const int cj = colat_old[j];
+    // (a) winner of the previous launch's candidates (every wave, identical result)
+    double bv = -1.0;
+    int bp = 0x7fffffff, bc = -1;
+    for (int e = ln; e < gact; e += WAVE) {
+        const QdCand cd = cand_old[e];
+        if (qd_better(cd.val, cd.pos, bv, bp)) {
+            bv = cd.val;
+            bp = cd.pos;
+            bc = cd.col;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off, WAVE);
+        const int op = __shfl_xor(bp, off, WAVE);
+        const int oc = __shfl_xor(bc, off, WAVE);
+        if (qd_better(ov, op, bv, bp)) {
+            bv = ov;
+            bp = op;
+            bc = oc;
+        }
+    }
+    const int p = bc;          // physical pivot column
+    const int q = bp;          // its logical position
+    // (b) reflector of the pivot column (rows j..kp-1)
+    double v[RPL];
+    double xn2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int r = j + ln + 64 * i;
+        v[i] = (r < kp) ? M[r + (size_t)p * a.ldr] : 0.0;
+        if (ln + 64 * i > 0) xn2 += v[i] * v[i];
+    }
+    xn2 = wave_allsum(xn2);
+    const double alpha = wave_bcast(v[0], 0);
+    const Reflector h = make_reflector(alpha, xn2);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) v[i] = (ln + 64 * i == 0) ? 1.0 : v[i] * h.scale;
+
+    // (c) own columns (both at once: the two reductions overlap)
+    double dot[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        dot[u] = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) dot[u] += x[u][i] * v[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) dot[u] = wave_allsum(dot[u]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int slot = 2 * w + u;
+        const int c = cbase + u;
+        double candv = -1.0;
+        int candp = 0x7fffffff;
+        if (c < ctot) {
+            if (c == p) {
+                // retire the pivot column: reflector by position, beta, tau
+                double* Vb = a.Vb + prob * a.sVb;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    const int r = j + ln + 64 * i;
+                    if (r < kp && ln + 64 * i > 0) Vb[r + (size_t)j * a.ldr] = v[i];
+                }
+                if (ln == 0) {
+                    a.diag[prob * a.sDiag + j] = h.beta;
+                    a.tau[prob * a.sTau + j] = h.tau;
+                    chosen[p] = j;
+                    pos_new[p] = j;
+                }
+            } else if (c == n2 || cst[u] < 0) {
+                if (h.tau != 0.0) {
+                    const double wd = h.tau * dot[u];
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) {
+                        const int r = j + ln + 64 * i;
+                        x[u][i] -= wd * v[i];
+                        if (r < kp) M[r + (size_t)c * a.ldr] = x[u][i];
+                    }
+                }
+                if (c < n2) {
+                    const double ajc = wave_bcast(x[u][0], 0);
+                    double o1 = cv1[u];
+                    const double o2 = cv2[u];
+                    if (o1 != 0.0) {
+                        double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
+                        temp = temp > 0.0 ? temp : 0.0;
+                        const double qq = o1 / o2;
+                        const double temp2 = temp * qq * qq;
+                        if (temp2 <= tol3z) {
+                            double s = 0.0;
+#pragma unroll
+                            for (int i = 0; i < RPL; ++i)
+                                if (ln + 64 * i > 0) s += x[u][i] * x[u][i];
+                            s = wave_allsum(s);
+                            o1 = (j + 1 < kp) ? sqrt(s) : 0.0;
+                            if (ln == 0) {
+                                vn1[c] = o1;
+                                vn2[c] = o1;
+                            }
+                        } else {
+                            o1 = o1 * sqrt(temp);
+                            if (ln == 0) vn1[c] = o1;
+                        }
+                    }
+                    const int np = (c == cj) ? q : cps[u];
+                    if (ln == 0) pos_new[c] = np;
+                    candv = o1;
+                    candp = np;
+                }
+            } else if (ln == 0) {
+                pos_new[c] = cps[u];   // already retired: keeps its position
+            }
+        }
+        if (ln == 0) {
+            cval[slot] = candv;
+            cpos[slot] = candp;
+        }
+    }
+    // (d) position -> column map for the positions this workgroup administers
+    if (threadIdx.x < QD_CPW) {
+        const int k = g * QD_CPW + threadIdx.x;
+        if (k < n2) colat_new[k] = (k == j) ? p : ((k == q) ? cj : colat_old[k]);
+    }
+    __syncthreads();
+    // (e) candidate for the next step
+    if (threadIdx.x == 0) {
+        double cv = -1.0;
+        int cp = 0x7fffffff, cc = -1;
+        for (int s = 0; s < QD_CPW; ++s)
+            if (qd_better(cval[s], cpos[s], cv, cp)) {
+                cv = cval[s];
+                cp = cpos[s];
+                cc = g * QD_CPW + s;
+            }
+        QdCand cd = {cv, cp, cc};
+        cand_new[g] = cd;
+    }
+}
+
+// gather the LAPACK-style compact factors in pivoted order + jpvt
+__global__ __launch_bounds__(256) void k_qd_assemble(QdArgs a) {
+    const int prob = blockIdx.y + a.prob0;
+    const ProbState st = a.state[prob];
+    const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
+    const int g = blockIdx.x;
+    if (kp == 0 || g * QD_CPW >= ctot) return;
+    const int par = kp & 1;
+    const int* colat = a.colat + prob * 2 * a.sI + par * a.sI;
+    const double* M = a.M + prob * a.sM;
+    const double* Vb = a.Vb + prob * a.sVb;
+    double* Rt = a.Rt + prob * a.sRt;
+    const int w = wave_id(), ln = lane_id();
+    for (int u = 0; u < 2; ++u) {
+        const int k = g * QD_CPW + 2 * w + u;   // position
+        if (k >= ctot) continue;
+        const int c = (k < n2) ? colat[k] : n2;
+        for (int r = ln; r < kp; r += WAVE) {
+            double v;
+            if (k < kp && k < n2) {
+                if (r < k) v = M[r + (size_t)c * a.ldr];
+                else if (r == k) v = a.diag[prob * a.sDiag + k];
+                else v = Vb[r + (size_t)k * a.ldr];
+            } else {
+                v = M[r + (size_t)c * a.ldr];
+            }
+            Rt[r + (size_t)k * a.ldr] = v;
+        }
+        if (ln == 0 && k < n2) a.jpvt[prob * a.sJ + k] = c + 1;
+    }
+}
+
+}  // namespace gn

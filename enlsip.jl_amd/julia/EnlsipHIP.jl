@@ -1,0 +1,185 @@
+# EnlsipHIP.jl — thin ccall glue that plugs libenlsip_gn.so underneath Enlsip.jl's
+# Gauss-Newton subproblem (gn_search_direction + the QR lines of update_working_set), leaving
+# CnlsModel / solve! and everything above the seam unchanged.
+#
+# STATUS: written against include/enlsip_gn.h and the reference sources, but NOT executed:
+# no Julia toolchain exists in the build container or on the GPU box (SURVEY.md §0, §8c).  The
+# same C ABI is exercised end to end by the ctypes host mirror (enlsip.jl_amd/python) and
+# tests/test_gpu_parity.py; INTEGRATION.md shows how a maintainer wires this file in.
+#
+# Seam (reference lines):
+#   update_working_set   src/enlsip_functions.jl:686-795   (QR lines :700, 722-725, 740-743, 758-762, 768-771, 786-789)
+#   gn_search_direction  src/enlsip_functions.jl:206-234
+#   sub_search_direction src/enlsip_functions.jl:116-153   (re-entered at :1253)
+module EnlsipHIP
+
+using LinearAlgebra
+
+const LIB = get(ENV, "ENLSIP_GN_LIB", joinpath(@__DIR__, "..", "lib", "libenlsip_gn.so"))
+
+const FACTOR_A = Cint(0)
+const FACTOR_L11 = Cint(1)
+const FACTOR_J2 = Cint(2)
+
+struct Opts
+    device::Int32
+    flags::Int32
+    panel_width::Int32
+    tile_rows::Int32
+    stream::Ptr{Cvoid}
+end
+
+struct Info
+    rankA::Int64
+    rankJ2::Int64
+    code::Int64
+    dimA::Int64
+    dimJ2::Int64
+    status::Int64
+end
+
+mutable struct Handle
+    ptr::Ptr{Cvoid}
+    function Handle(; device::Integer=-1, flags::Integer=0)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        opts = Ref(Opts(Int32(device), Int32(flags), Int32(0), Int32(0), C_NULL))
+        rc = ccall((:enlsip_gn_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{Opts}), ref, opts)
+        rc == 0 || error("enlsip_gn_create failed with code $rc")
+        h = new(ref[])
+        finalizer(x -> ccall((:enlsip_gn_destroy, LIB), Cint, (Ptr{Cvoid},), x.ptr), h)
+        return h
+    end
+end
+
+function check(h::Handle, rc::Integer)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:enlsip_gn_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr))
+    error("libenlsip_gn error $rc: $msg")
+end
+
+# QRPivoted-like shim backed by the device-resident factors of the last solve on `h`
+# (valid until the next solve).  Supports exactly what the reference's consumers use:
+# F.R, F.p, F.P, F.Q' * v, F.Q * v  (src/enlsip_functions.jl:461-537, 1118-1291).
+struct DeviceQR
+    h::Handle
+    which::Cint
+    rows::Int      # length of vectors Q acts on
+end
+
+function factor_shape(F::DeviceQR)
+    r = Ref{Int64}(0); c = Ref{Int64}(0)
+    check(F.h, ccall((:enlsip_gn_factor_shape, LIB), Cint, (Ptr{Cvoid}, Cint, Int64, Ref{Int64}, Ref{Int64}),
+                     F.h.ptr, F.which, 0, r, c))
+    return r[], c[]
+end
+
+function Base.getproperty(F::DeviceQR, s::Symbol)
+    if s === :R
+        r, c = factor_shape(F)
+        R = zeros(Float64, max(r, 1), c)
+        GC.@preserve R check(F.h, ccall((:enlsip_gn_get_R, LIB), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Int64),
+                                        getfield(F, :h).ptr, getfield(F, :which), 0, R, max(r, 1)))
+        return R[1:r, :]
+    elseif s === :p
+        _, c = factor_shape(F)
+        p = zeros(Int64, c)
+        c > 0 && GC.@preserve p check(getfield(F, :h), ccall((:enlsip_gn_get_jpvt, LIB), Cint,
+                                      (Ptr{Cvoid}, Cint, Int64, Ptr{Int64}), getfield(F, :h).ptr, getfield(F, :which), 0, p))
+        return p
+    elseif s === :P
+        p = F.p
+        n = length(p)
+        P = zeros(Float64, n, n)
+        for i in 1:n
+            P[p[i], i] = 1.0
+        end
+        return P
+    elseif s === :Q
+        return DeviceQ(F, false)
+    else
+        return getfield(F, s)
+    end
+end
+
+struct DeviceQ
+    F::DeviceQR
+    adj::Bool
+end
+Base.adjoint(Q::DeviceQ) = DeviceQ(Q.F, !Q.adj)
+
+function Base.:*(Q::DeviceQ, v::AbstractVector{Float64})
+    out = Vector{Float64}(v)
+    f = Q.adj ? :enlsip_gn_apply_qt : :enlsip_gn_apply_q
+    h = getfield(Q.F, :h)
+    GC.@preserve out begin
+        rc = Q.adj ?
+            ccall((:enlsip_gn_apply_qt, LIB), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}), h.ptr, getfield(Q.F, :which), 0, out) :
+            ccall((:enlsip_gn_apply_q, LIB), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}), h.ptr, getfield(Q.F, :which), 0, out)
+        check(h, rc)
+    end
+    return out
+end
+
+# J * F_A.Q  (src/enlsip_functions.jl:219, :526, :1249): served from the device instead of a second dormqr
+function jq1(h::Handle, m::Integer, n::Integer)
+    out = zeros(Float64, m, n)
+    GC.@preserve out check(h, ccall((:enlsip_gn_get_JQ1, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64), h.ptr, 0, out, m))
+    return out
+end
+
+"""
+    gn_search_direction_hip!(h, J, rx, A_active, cx, ε_rank, current_iter) -> p_gn, F_A, F_L11, F_J2
+
+Replaces, in `update_working_set`, every occurrence of
+
+    F_A = qr(C.A', ColumnNorm()); rankA = pseudo_rank(diag(F_A.R), ε_rank)
+    F_L11 = qr(F_A.R', ColumnNorm())
+    p_gn[:], F_J2 = gn_search_direction(J, rx, C.cx, F_A, F_L11, rankA, W.t, ε_rank, iter_k)
+
+(src/enlsip_functions.jl:722-725, 740-743, 758-762, 768-771, 786-789) by one call into the HIP
+library, and writes the same `Iteration` fields gn_search_direction writes (:226-231).
+`A_active` is `C.A` (t x n); its transpose is materialised because the ABI wants `C.A'` column-major.
+"""
+function gn_search_direction_hip!(h::Handle, J::Matrix{Float64}, rx::Vector{Float64}, A_active::Matrix{Float64},
+                                  cx::Vector{Float64}, ε_rank::Float64, current_iter)
+    m, n = size(J)
+    t = size(A_active, 1)
+    At = Matrix{Float64}(transpose(A_active))          # n x t, column-major
+    p = zeros(Float64, n); b = zeros(Float64, t); d = zeros(Float64, m)
+    info = Ref(Info(0, 0, 0, 0, 0, 0))
+    jA = zeros(Int64, t); jL = zeros(Int64, min(n, t)); jJ = zeros(Int64, n)
+    GC.@preserve J rx At cx p b d jA jL jJ begin
+        rc = ccall((:enlsip_gn_solve, LIB), Cint,
+                   (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64,
+                    Ptr{Float64}, Float64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Info},
+                    Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+                   h.ptr, m, n, t, J, m, rx, At, max(n, 1), cx, ε_rank, -1, -1, p, b, d, info, jA, jL, jJ)
+        check(h, rc)
+    end
+    i = info[]
+    (i.status & 1) != 0 && throw(LinearAlgebra.SingularException(0))   # Julia's `\` would have thrown
+    current_iter.rankA = i.rankA
+    current_iter.rankJ2 = i.rankJ2
+    current_iter.dimA = i.rankA
+    current_iter.dimJ2 = i.rankJ2
+    current_iter.b_gn = b
+    current_iter.d_gn = d
+    return p, DeviceQR(h, FACTOR_A, n), DeviceQR(h, FACTOR_L11, t), DeviceQR(h, FACTOR_J2, m)
+end
+
+"""
+    sub_search_direction_hip(h, m, n, t, dimA, dimJ2, code) -> p, b, d
+
+Re-entry of `sub_search_direction` on the resident factors with truncated dimensions
+(src/enlsip_functions.jl:1253, subspace minimisation).  SURVEY §7 H1: callers that slice
+`d_gn[1:k]` must keep `k <= n - rankA`; assert that in the caller.
+"""
+function sub_search_direction_hip(h::Handle, m::Integer, n::Integer, t::Integer, dimA::Integer, dimJ2::Integer, code::Integer)
+    p = zeros(Float64, n); b = zeros(Float64, t); d = zeros(Float64, m)
+    GC.@preserve p b d check(h, ccall((:enlsip_gn_resolve, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        h.ptr, 0, dimA, dimJ2, code, p, b, d))
+    return p, b, d
+end
+
+end # module

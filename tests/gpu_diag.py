@@ -77,6 +77,15 @@ def main():
         ("two_level", synth.make_problem, (1500, 70, 5)),
         ("mid", synth.make_problem, (2048, 128, 16)),
     ]
+    if mode == "c2":
+        s = GNSolver(device=0)
+        J, rx, A, cx = synth.make_problem(900, 4096, 512, 64)
+        check(s, "c2", J, rx, A, cx)
+        s.set_profiling(True)
+        for rep in range(3):
+            s.solve(J, rx, A, cx)
+            print("    stage ms", {k: round(v, 3) for k, v in s.stage_ms().items()}, "update", s.update_stats(), flush=True)
+        return 0
     if mode == "full":
         cases += [("c2", synth.make_problem, (4096, 512, 64)), ("three_level", synth.make_problem, (20000, 40, 3))]
     for flags, label in ((0, "mfma"), (FLAG_UPDATE_REFLECTORS, "refl")):
