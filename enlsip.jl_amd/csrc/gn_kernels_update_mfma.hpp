@@ -78,10 +78,10 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
         for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
 
     const int vrow = tid & 63, vcg = tid >> 6;
-#pragma unroll
-    for (int ch = 0; ch < RPL; ++ch) {
-        __syncthreads();  // previous chunk's operands fully consumed
-        // stage V chunk (unit lower trapezoid masked in)
+    // V chunk loader: 8 values per thread (row vrow of the chunk, columns vcg + 4u), unit lower
+    // trapezoid masked in.  The loads of chunk ch+1 are issued before the MFMAs of chunk ch so the
+    // L2 latency overlaps with the matrix pipe (the data are only waited for at the next LDS write).
+    auto load_v = [&](int ch, double* vr) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = vcg + 4 * u;
@@ -91,8 +91,18 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
                 if (s > j) v = Wm[tile_row0 + s + (size_t)(col0 + j) * a.ldw];
                 else if (s == j) v = 1.0;
             }
-            Vl[j * UM_LD + vrow] = v;
+            vr[u] = v;
         }
+    };
+    double vreg[8];
+    load_v(0, vreg);
+#pragma unroll
+    for (int ch = 0; ch < RPL; ++ch) {
+        __syncthreads();  // previous chunk's operands fully consumed
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Vl[(vcg + 4 * u) * UM_LD + vrow] = vreg[u];
+        if (ch + 1 < RPL) load_v(ch + 1, vreg);
+        else load_v(0, vreg);   // first chunk of the second product
         // stage C chunk from registers
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -155,16 +165,8 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
     for (int ch = 0; ch < RPL; ++ch) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = vcg + 4 * u;
-            const int s = 64 * ch + vrow;
-            double v = 0.0;
-            if (j < bw && s < rows_valid) {
-                if (s > j) v = Wm[tile_row0 + s + (size_t)(col0 + j) * a.ldw];
-                else if (s == j) v = 1.0;
-            }
-            Vl[j * UM_LD + vrow] = v;
-        }
+        for (int u = 0; u < 8; ++u) Vl[(vcg + 4 * u) * UM_LD + vrow] = vreg[u];
+        if (ch + 1 < RPL) load_v(ch + 1, vreg);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
