@@ -8,7 +8,7 @@ Workload (config.workload): BASELINE configs[1] "C2" — dense synthetic CNLS su
 m=4096 residuals, n=512 parameters, t=64 active (equality) constraints, fp64.  One *step* is one
 pass of the hot path (src/enlsip_functions.jl:700, 768-771, 206-234, 116-153 of the reference)
 over one batch of `--batch` independent subproblems that are already resident in HBM; the batch
-(default 32 problems = 537 MB of Jacobians) is larger than the 256 MB Infinity Cache so the
+(default 256 problems = 4.3 GB of Jacobians) is larger than the 256 MB Infinity Cache so the
 traffic is real HBM traffic.  value = problems solved by all ranks / wall time of the K timed
 steps (barrier + synchronize on both sides, MAX over ranks).  Ranks shard independent
 subproblems: no collective on the data path (weak scaling).
@@ -41,7 +41,9 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="independent C2 subproblems per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="independent C2 subproblems per GPU per step")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the batch over this many handles/HIP streams driven by host threads")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--t", type=int, default=64)
@@ -85,11 +87,26 @@ def main() -> int:
     torch.cuda.synchronize()
 
     solver = GNSolver(device=local_rank)
+    S = max(1, min(args.streams, B))
+    solvers = [solver] + [GNSolver(device=local_rank) for _ in range(S - 1)]
+    bounds = [(B * i) // S for i in range(S + 1)]
+
+    def part(i):
+        lo, hi = bounds[i], bounds[i + 1]
+        solvers[i].solve_batched_dev(hi - lo, m, n, t, J[lo].data_ptr(), m, m * n, rx[lo].data_ptr(),
+                                     At[lo].data_ptr(), n, n * t, cx[lo].data_ptr(), SQRT_EPS,
+                                     dp=p[lo].data_ptr(), db=b[lo].data_ptr(), dd=d[lo].data_ptr(),
+                                     djJ=jJ[lo].data_ptr())
+
+    if S > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=S)
 
     def step():
-        solver.solve_batched_dev(B, m, n, t, J.data_ptr(), m, m * n, rx.data_ptr(), At.data_ptr(), n, n * t,
-                                 cx.data_ptr(), SQRT_EPS, dp=p.data_ptr(), db=b.data_ptr(), dd=d.data_ptr(),
-                                 djJ=jJ.data_ptr())
+        if S == 1:
+            part(0)
+        else:
+            list(pool.map(part, range(S)))     # ctypes releases the GIL: the S streams run concurrently
 
     def barrier():
         torch.cuda.synchronize()
@@ -171,7 +188,7 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": "C2: batch of independent dense CNLS subproblems, m=4096 n=512 t=64 fp64, "
                                    "inputs resident in HBM", "m": m, "n": n, "t": t,
-                       "batch_per_gpu": B, "parallelism": f"independent subproblems x{world}"},
+                       "batch_per_gpu": B, "streams_per_gpu": S, "parallelism": f"independent subproblems x{world}"},
             "single_problem_latency_ms": round(lat_ms, 3),
             "results_check": {"finite": ok, "max_constraint_residual_problem0": cons},
             "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_step": stage_ms,

@@ -18,6 +18,7 @@
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_qrcp_dist.hpp"
 #include "gn_kernels_qrcp_persist.hpp"
+#include "gn_kernels_qrcp_block.hpp"
 
 using namespace gn;
 
@@ -99,9 +100,9 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     const long long per_dbl = P.sFA + P.sTauA + P.sFL + P.sTauL + P.sTA + P.sP1 + P.sB + P.sW + P.sT + P.sRt +
                               P.sTauJ + P.sZ + P.sVec + P.sM + P.sVb + P.sDiag + 2 * P.sVn;
     const long long per_i64 = P.sJA + P.sJL + P.sJJ;
-    const long long per_i32 = 5 * P.sQI;   // chosen + 2 x pos + 2 x colat
+    const long long per_i32 = 6 * P.sQI;   // chosen + 2 x pos + 2 x colat + inblk
     const size_t bytes = (size_t)batch * (per_dbl * 8 + per_i64 * 8 + per_i32 * 4 + P.sCand * sizeof(QdCand)) +
-                         (size_t)batch * sizeof(ProbState) + 8192;
+                         (size_t)batch * (sizeof(ProbState) + sizeof(SbInfo)) + 8192;
     int rc = grow(h, h->ws, bytes);
     if (rc) return rc;
     char* p = (char*)h->ws.p;
@@ -126,10 +127,17 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     h->state = (ProbState*)p;
     p += (((size_t)batch * sizeof(ProbState) + 255) / 256) * 256;
     h->abort_word = (unsigned*)p;
+    p += 256;
+    h->sbInfo = (void*)p;
+    p += (((size_t)batch * sizeof(SbInfo) + 255) / 256) * 256;
+    h->sbInblk = (int*)p;
     if (h->h_state_cap < (size_t)batch) {
         if (h->h_state) GN_HIP(hipHostFree(h->h_state));
         h->h_state = nullptr;
         GN_HIP(hipHostMalloc((void**)&h->h_state, (size_t)batch * sizeof(ProbState), hipHostMallocDefault));
+        if (h->h_sbinfo) GN_HIP(hipHostFree(h->h_sbinfo));
+        h->h_sbinfo = nullptr;
+        GN_HIP(hipHostMalloc(&h->h_sbinfo, (size_t)batch * sizeof(SbInfo), hipHostMallocDefault));
         h->h_state_cap = (size_t)batch;
     }
     h->have_plan = true;
@@ -279,6 +287,73 @@ static int run_qrcp_dist(enlsip_gn_handle h, int n2_launch) {
     return 0;
 }
 
+// blocked pivoted QR of R0 with verified pivots (gn_kernels_qrcp_block.hpp)
+static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
+    const Plan& P = h->plan;
+    const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
+    SbArgs a{};
+    QdArgs& q = a.q;
+    q.n = (int)P.n; q.ldw = P.ldw; q.ldr = P.ldr; q.step = -1; q.prob0 = 0;
+    q.W = h->W; q.sW = P.sW; q.M = h->qdM; q.sM = P.sM; q.Vb = h->qdVb; q.sVb = P.sVb; q.Rt = h->Rt; q.sRt = P.sRt;
+    q.tau = h->tauJ; q.sTau = P.sTauJ; q.diag = h->qdDiag; q.sDiag = P.sDiag;
+    q.vn1 = h->qdVn1; q.vn2 = h->qdVn2; q.sVn = P.sVn;
+    q.chosen = h->qdChosen; q.pos = h->qdPos; q.colat = h->qdColat; q.sI = P.sQI;
+    q.cand = (QdCand*)h->qdCand; q.sCand = P.sCand; q.Gmax = P.qdGmax;
+    q.jpvt = h->jpvtJ; q.sJ = P.sJJ; q.state = h->state;
+    a.info = (SbInfo*)h->sbInfo; a.inblk = h->sbInblk; a.sIn = P.sQI; a.blkid = 0;
+    a.dbg = nullptr;
+    if (getenv("ENLSIP_GN_SB_DEBUG")) {   // diagnostic: per-block phase stamps of problem 0 into the scratch buffer
+        if (grow(h, h->scratch, 8 * 8 * 1024) == 0) {
+            a.dbg = (long long*)h->scratch.p;
+            (void)hipMemsetAsync(a.dbg, 0, 8 * 8 * 1024, h->stream);
+        }
+    }
+    const int G = (n2_launch + 1 + QD_CPW - 1) / QD_CPW;
+    dim3 grid(G, (unsigned)P.batch);
+    const bool big = kp_launch > 512;
+    hipStream_t s = h->stream;
+    if (big) hipLaunchKernelGGL(k_qd_init<16>, grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL(k_sb_reset, dim3(((unsigned)P.n + 255) / 256, (unsigned)P.batch), dim3(256), 0, s, a, (int)P.n);
+    const size_t lds = sizeof(SbLds);
+    if (big) big_lds(k_sb_factor<16>, lds); else big_lds(k_sb_factor<8>, lds);
+    int it = 0;
+    int chunk = std::min(kp_launch, 22);   // ~20 blocks factor a C2 problem; re-check in small chunks after that
+    SbInfo* hinfo = (SbInfo*)h->h_sbinfo;
+    while (it < kp_launch) {
+        for (int i = 0; i < chunk && it < kp_launch; ++i, ++it) {
+            a.blkid = it;
+            if (big) {
+                hipLaunchKernelGGL(k_sb_factor<16>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
+                hipLaunchKernelGGL(k_sb_update<16>, grid, dim3(256), 0, s, a);
+            } else {
+                hipLaunchKernelGGL(k_sb_factor<8>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
+                hipLaunchKernelGGL(k_sb_update<8>, grid, dim3(256), 0, s, a);
+            }
+        }
+        GN_HIP(hipGetLastError());
+        GN_HIP(hipMemcpyAsync(hinfo, h->sbInfo, (size_t)P.batch * sizeof(SbInfo), hipMemcpyDeviceToHost, s));
+        GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)P.batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
+        GN_HIP(hipStreamSynchronize(s));
+        bool done = true;
+        for (long long k = 0; k < P.batch; ++k) done = done && (hinfo[k].j0 >= h->h_state[k].kp);
+        if (done) break;
+        chunk = 4;
+    }
+    hipLaunchKernelGGL(k_qd_assemble, grid, dim3(256), 0, s, q);
+    GN_HIP(hipGetLastError());
+    if (a.dbg) {
+        std::vector<long long> hd(8 * 64);
+        GN_HIP(hipMemcpyAsync(hd.data(), a.dbg, hd.size() * 8, hipMemcpyDeviceToHost, s));
+        GN_HIP(hipStreamSynchronize(s));
+        for (int b = 0; b < 64 && hd[b * 8] != 0; ++b)
+            fprintf(stderr, "sb block %2d: steps %3lld | keys+rank %6.2f us, load %6.2f, steps %7.2f, flush %5.2f, writeback-start %5.2f\n", b, hd[b * 8 + 5],
+                    (hd[b * 8 + 1] - hd[b * 8]) * 0.01, (hd[b * 8 + 2] - hd[b * 8 + 1]) * 0.01, (hd[b * 8 + 3] - hd[b * 8 + 2]) * 0.01,
+                    (hd[b * 8 + 4] - hd[b * 8 + 3]) * 0.01, 0.0);
+    }
+    return 0;
+}
+
 // persistent LDS-resident pivoted QR of R0: G co-resident workgroups per problem, chunks of problems
 static int run_qrcp_persist(enlsip_gn_handle h, int n2_launch) {
     const Plan& P = h->plan;
@@ -393,11 +468,16 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         {
             const int kp_launch = (int)std::min<long long>(m, n2_launch);
             if ((size_t)kp_launch * (n2_launch + 1) > (size_t)CMAT_DOUBLES) {
-                rc = (h->qrcp_mode == 0) ? run_qrcp_persist(h, n2_launch) : -1;
-                if (rc > 0) return rc;
-                if (rc < 0) {   // shape not supported by the persistent kernel (or it is disabled)
-                    rc = run_qrcp_dist(h, n2_launch);
+                if (h->qrcp_mode == 2) {
+                    rc = run_qrcp_block(h, n2_launch);
                     if (rc) return rc;
+                } else {
+                    rc = (h->qrcp_mode == 0) ? run_qrcp_persist(h, n2_launch) : -1;
+                    if (rc > 0) return rc;
+                    if (rc < 0) {   // shape not supported by the persistent kernel (or it is disabled)
+                        rc = run_qrcp_dist(h, n2_launch);
+                        if (rc) return rc;
+                    }
                 }
                 fa.refactor = 2;
             }
@@ -491,7 +571,9 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         const char* qm = getenv("ENLSIP_GN_QRCP");
         // ENLSIP_GN_QRCP=persist selects the co-resident LDS kernel; default: one launch per pivot step
         // (measured faster on MI355X for both batch = 1 and batch = 32, profiles/r1_notes.md)
-        h->qrcp_mode = (qm && qm[0] == 'p') ? 0 : 1;
+        h->qrcp_mode = 2;                                    // default: blocked with verified pivots
+        if (qm && qm[0] == 'p') h->qrcp_mode = 0;            // persist
+        if (qm && qm[0] == 's') h->qrcp_mode = 1;            // step: one launch per pivot step
     }
     if (opts && opts->panel_width != 0 && opts->panel_width != PB) {
         delete h;
@@ -526,6 +608,7 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->in_stage.p) (void)hipFree(h->in_stage.p);
     if (h->out_stage.p) (void)hipFree(h->out_stage.p);
     if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->h_sbinfo) (void)hipHostFree(h->h_sbinfo);
     if (h->ev_ready)
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->upd_ev) (void)hipEventDestroy(e);

@@ -64,8 +64,11 @@ struct enlsip_gn_context {
     int *qdChosen = nullptr, *qdPos = nullptr, *qdColat = nullptr;
     void* qdCand = nullptr;
     unsigned* abort_word = nullptr;
+    void* sbInfo = nullptr;      // SbInfo per problem (device)
+    int* sbInblk = nullptr;      // per column block id (device)
+    void* h_sbinfo = nullptr;    // pinned mirror of sbInfo
     int cu_count = 256;
-    int qrcp_mode = 0;   // 0 persistent (LDS-resident, co-resident workgroups), 1 one launch per pivot step
+    int qrcp_mode = 2;   // 0 persistent (co-resident workgroups), 1 one launch per pivot step, 2 blocked with verified pivots
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
     gn::ProbState* state = nullptr;
     // staging for the host-pointer API

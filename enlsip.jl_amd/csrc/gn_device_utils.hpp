@@ -51,6 +51,53 @@ __device__ __forceinline__ double wave_allsum(double x) {
     return (r0 + r1) + (r2 + r3);
 }
 
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+
+// Wave arg-max with LAPACK's idamax tie rule on (value, position): larger value wins, equal values
+// -> lower position wins.  Returns the same (val, pos, idx) in every lane.  DPP butterflies inside
+// the rows of 16 lanes, then the four row winners are combined through SGPRs.
+struct ArgMax {
+    double val;
+    int pos, idx;
+};
+__device__ __forceinline__ bool am_better(double v, int p, double bv, int bp) {
+    return v > bv || (v == bv && p < bp);
+}
+template <int CTRL>
+__device__ __forceinline__ void am_step(ArgMax& a) {
+    const double ov = dpp_f64<CTRL>(a.val);
+    const int op = dpp_i32<CTRL>(a.pos);
+    const int oi = dpp_i32<CTRL>(a.idx);
+    if (am_better(ov, op, a.val, a.pos)) {
+        a.val = ov;
+        a.pos = op;
+        a.idx = oi;
+    }
+}
+__device__ __forceinline__ ArgMax wave_argmax(double val, int pos, int idx) {
+    ArgMax a = {val, pos, idx};
+    am_step<0xB1>(a);
+    am_step<0x4E>(a);
+    am_step<0x141>(a);
+    am_step<0x140>(a);
+    ArgMax r = {readlane_f64(a.val, 0), __builtin_amdgcn_readlane(a.pos, 0), __builtin_amdgcn_readlane(a.idx, 0)};
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+        const double ov = readlane_f64(a.val, 16 * row);
+        const int op = __builtin_amdgcn_readlane(a.pos, 16 * row);
+        const int oi = __builtin_amdgcn_readlane(a.idx, 16 * row);
+        if (am_better(ov, op, r.val, r.pos)) {
+            r.val = ov;
+            r.pos = op;
+            r.idx = oi;
+        }
+    }
+    return r;
+}
+
 // src_lane must be wave-uniform (it is a loop counter everywhere it is used): v_readlane
 __device__ __forceinline__ double wave_bcast(double x, int src_lane) {
     return readlane_f64(x, src_lane);

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_qd_assemble(QdArgs a) {
     const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
     const int g = blockIdx.x;
     if (kp == 0 || g * QD_CPW >= ctot) return;
-    const int par = kp & 1;
+    const int par = (a.step < 0) ? 0 : (kp & 1);   // block form keeps a single (parity 0) map
     const int* colat = a.colat + prob * 2 * a.sI + par * a.sI;
     const double* M = a.M + prob * a.sM;
     const double* Vb = a.Vb + prob * a.sVb;
