@@ -317,6 +317,7 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     hipLaunchKernelGGL(k_sb_reset, dim3(((unsigned)P.n + 255) / 256, (unsigned)P.batch), dim3(256), 0, s, a, (int)P.n);
     const size_t lds = sizeof(SbLds);
     if (big) big_lds(k_sb_factor<16>, lds); else big_lds(k_sb_factor<8>, lds);
+    dim3 ugrid((n2_launch + 1 + SB_UCW - 1) / SB_UCW, (unsigned)P.batch);
     int it = 0;
     int chunk = std::min(kp_launch, 22);   // ~20 blocks factor a C2 problem; re-check in small chunks after that
     SbInfo* hinfo = (SbInfo*)h->h_sbinfo;
@@ -325,10 +326,10 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
             a.blkid = it;
             if (big) {
                 hipLaunchKernelGGL(k_sb_factor<16>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
-                hipLaunchKernelGGL(k_sb_update<16>, grid, dim3(256), 0, s, a);
+                hipLaunchKernelGGL(k_sb_update<16>, ugrid, dim3(256), 0, s, a);
             } else {
                 hipLaunchKernelGGL(k_sb_factor<8>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
-                hipLaunchKernelGGL(k_sb_update<8>, grid, dim3(256), 0, s, a);
+                hipLaunchKernelGGL(k_sb_update<8>, ugrid, dim3(256), 0, s, a);
             }
         }
         GN_HIP(hipGetLastError());
@@ -612,6 +613,7 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->ev_ready)
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->upd_ev) (void)hipEventDestroy(e);
+    if (h->sub) (void)enlsip_gn_destroy(h->sub);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -739,3 +741,4 @@ int enlsip_gn_solve(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const d
 }  // extern "C"
 
 #include "gn_accessors.inc"
+#include "gn_tsqr.inc"

@@ -68,6 +68,8 @@ struct enlsip_gn_context {
     int* sbInblk = nullptr;      // per column block id (device)
     void* h_sbinfo = nullptr;    // pinned mirror of sbInfo
     int cu_count = 256;
+    enlsip_gn_context* sub = nullptr;   // handle for the stacked problem of the TSQR combine stage
+    long long tsqr_n2 = -1;             // n2 of the last tsqr_local on this handle
     int qrcp_mode = 2;   // 0 persistent (co-resident workgroups), 1 one launch per pivot step, 2 blocked with verified pivots
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
     gn::ProbState* state = nullptr;

@@ -37,18 +37,68 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// Wave all-reduce on the DPP crossbar instead of ds_bpermute (no LDS-latency chain): four
-// butterfly steps inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
-// row_mirror), then the four row sums are read to SGPRs and added in a fixed order, so every
-// lane ends with the same bits.
+// butterfly partner sums across the 16-lane rows with gfx950's v_permlane16_swap / v_permlane32_swap
+// (VALU, no LDS crossbar): with vdst = vsrc = x the swap leaves {r0,r0,r2,r2} / {r1,r1,r3,r3}
+// (rows) resp. {lo,lo} / {hi,hi} (32-lane halves), whose sum is the xor-16 / xor-32 butterfly.
+__device__ __forceinline__ double xor16_sum(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double xor32_sum(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// Wave all-reduce without LDS traffic: four DPP butterflies inside each row of 16 lanes
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the xor-16 / xor-32 row butterflies.
+// Every level adds the two partners' partial sums (a + b == b + a), so all lanes end with the
+// same bits.
 __device__ __forceinline__ double wave_allsum(double x) {
     x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
     x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
     x += dpp_f64<0x141>(x);   // row_half_mirror
     x += dpp_f64<0x140>(x);   // row_mirror
-    const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16);
-    const double r2 = readlane_f64(x, 32), r3 = readlane_f64(x, 48);
-    return (r0 + r1) + (r2 + r3);
+    x = xor16_sum(x);
+    return xor32_sum(x);
+}
+
+// Eight simultaneous wave all-reduces ("transposed" butterfly): at every DPP level a lane hands
+// half of its partial sums to its partner and keeps the other half, so 8 -> 4 -> 2 -> 1 values are
+// moved instead of 8 each time.  Partner order row_mirror (i^15), row_half_mirror (i^7),
+// quad_perm [3,2,1,0] (i^3), quad_perm [1,0,3,2] (i^1): each partner keeps the same column set as
+// the lane (the set is decided by the lane bits the partner shares).  After the row levels lane l
+// holds column 4*bit3 + 2*bit2 + bit1; two row butterflies finish the sum and 8 readlanes
+// broadcast it.  out[c] is identical in all lanes.
+__device__ __forceinline__ void wave_allsum8(const double (&d)[8], double (&out)[8]) {
+    const int ln = threadIdx.x & 63;
+    const bool b3 = (ln & 8) != 0, b2 = (ln & 4) != 0, b1 = (ln & 2) != 0;
+    double k4[4], k2[2], k1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double mine = b3 ? d[c + 4] : d[c];
+        const double give = b3 ? d[c] : d[c + 4];
+        k4[c] = mine + dpp_f64<0x140>(give);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const double mine = b2 ? k4[c + 2] : k4[c];
+        const double give = b2 ? k4[c] : k4[c + 2];
+        k2[c] = mine + dpp_f64<0x141>(give);
+    }
+    {
+        const double mine = b1 ? k2[1] : k2[0];
+        const double give = b1 ? k2[0] : k2[1];
+        k1 = mine + dpp_f64<0x1B>(give);     // quad_perm [3,2,1,0]
+    }
+    k1 += dpp_f64<0xB1>(k1);                 // quad_perm [1,0,3,2]
+    k1 = xor16_sum(k1);
+    k1 = xor32_sum(k1);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[c] = readlane_f64(k1, 8 * (c >> 2) + 4 * ((c >> 1) & 1) + 2 * (c & 1));
 }
 
 template <int CTRL>

@@ -125,19 +125,19 @@ __global__ __launch_bounds__(256) void k_caqr_factor(CaqrArgs a) {
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) dot[cc] += x[cc][i] * v[i];
                 }
-#pragma unroll
-                for (int cc = 0; cc < 8; ++cc) dot[cc] = wave_allsum(dot[cc]);
+                double ds[8];
+                wave_allsum8(dot, ds);     // eight reductions for the price of ~three
 #pragma unroll
                 for (int cc = 0; cc < 8; ++cc) {
                     const int c = w + 4 * cc;
                     if (c > j) {
-                        const double wd = tj * dot[cc];
+                        const double wd = tj * ds[cc];
 #pragma unroll
                         for (int i = 0; i < RPL; ++i) x[cc][i] -= wd * v[i];
                     } else if (c < j) {
                         // Gram entry v_c' v_j for the T factor: rows above slot j are masked by
                         // v (zero there), so the R entries held in x[cc] do not contribute
-                        if (ln == 0) gsh[c][j] = dot[cc];
+                        if (ln == 0) gsh[c][j] = ds[cc];
                     }
                 }
             }
@@ -260,11 +260,11 @@ __global__ __launch_bounds__(256) void k_caqr_update_refl(CaqrArgs a) {
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) dot[cc] += x[cc][i] * v[i];
             }
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) dot[cc] = wave_allsum(dot[cc]);
+            double ds[8];
+            wave_allsum8(dot, ds);
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
-                const double wd = tj * dot[cc];
+                const double wd = tj * ds[cc];
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) x[cc][i] -= wd * v[i];
             }

@@ -328,8 +328,12 @@ __global__ __launch_bounds__(1024) void k_sb_factor(SbArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// apply the block's reflectors to every column that was not a candidate (+ the right-hand side)
+// apply the block's reflectors to every column that was not a candidate (+ the right-hand side).
+// A wave owns 8 columns: the 8 dot products share one transposed reduction, and the scalar norm
+// downdates of the 8 columns run as ONE instruction stream in lanes 0..7 (lane u = column u).
 // ---------------------------------------------------------------------------------------------
+constexpr int SB_UCW = 32;   // columns per workgroup of the update kernel (8 per wave)
+
 template <int RPL>
 __global__ __launch_bounds__(256) void k_sb_update(SbArgs a) {
     const int prob = blockIdx.y + a.q.prob0;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void k_sb_update(SbArgs a) {
     if (info.blk != a.blkid || info.s == 0) return;     // this problem did no step in this block
     const int jb = info.pad, s = info.s;
     const int g = blockIdx.x;
-    if (g * QD_CPW >= ctot) return;
+    if (g * SB_UCW >= ctot) return;
     const int ln = lane_id(), w = wave_id();
     double* M = a.q.M + prob * a.q.sM;
     const double* Vb = a.q.Vb + prob * a.q.sVb;
@@ -350,23 +354,27 @@ __global__ __launch_bounds__(256) void k_sb_update(SbArgs a) {
     const int* inblk = a.inblk + prob * a.sIn;
     const double tol3z = 1.4901161193847656e-08;
     const int rows = kp - jb;
+    const int cbase = g * SB_UCW + 8 * w;
 
-    const int cbase = g * QD_CPW + 2 * w;
-    bool act[2];
-    double x[2][RPL], o1[2], o2[2];
+    // lane u (< 8) carries the scalar state of column cbase + u
+    const int myc = cbase + (ln & 7);
+    const bool my_act = (myc == n2) || (myc < n2 && chosen[myc] < 0 && inblk[myc] != a.blkid);
+    double my_o1 = (my_act && myc < n2) ? vn1[myc] : 0.0;
+    double my_o2 = (my_act && myc < n2) ? vn2[myc] : 1.0;
+    const unsigned actmask = (unsigned)(__ballot(my_act && ln < 8) & 0xffull);
+    if (actmask == 0u) return;
+
+    double x[8][RPL];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 8; ++u) {
+        const bool act = (actmask >> u) & 1u;
         const int c = cbase + u;
-        act[u] = (c == n2) || (c < n2 && chosen[c] < 0 && inblk[c] != a.blkid);
-        o1[u] = (act[u] && c < n2) ? vn1[c] : 0.0;
-        o2[u] = (act[u] && c < n2) ? vn2[c] : 1.0;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             const int r = ln + 64 * i;
-            x[u][i] = (act[u] && r < rows) ? M[(jb + r) + (size_t)c * a.q.ldr] : 0.0;
+            x[u][i] = (act && r < rows) ? M[(jb + r) + (size_t)c * a.q.ldr] : 0.0;
         }
     }
-    if (!act[0] && !act[1]) return;
     auto load_v = [&](int t, double* v) {
         // reflector of step jb + t in block-local rows: zero above t, one at t
 #pragma unroll
@@ -380,61 +388,72 @@ __global__ __launch_bounds__(256) void k_sb_update(SbArgs a) {
     for (int t = 0; t < s; ++t) {
         if (t + 1 < s) load_v(t + 1, vn);
         const double tj = tau[jb + t];
-        double dot[2];
+        double dot[8], ds[8];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 8; ++u) {
             dot[u] = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) dot[u] += x[u][i] * v[i];
         }
+        wave_allsum8(dot, ds);
+        double ajc = 0.0;   // entry of row jb + t of "my" column: local row t lives in lane t & 63, register t >> 6
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dot[u] = wave_allsum(dot[u]);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 8; ++u) {
             if (tj != 0.0) {
-                const double wd = tj * dot[u];
+                const double wd = tj * ds[u];
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) x[u][i] -= wd * v[i];
             }
-            // entry of row jb + t: local row t lives in lane t & 63, register t >> 6
-            double ajc = 0.0;
+            double au = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i)
-                if ((t >> 6) == i) ajc = wave_bcast(x[u][i], t & 63);
-            if (o1[u] != 0.0) {
-                double temp = 1.0 - (fabs(ajc) / o1[u]) * (fabs(ajc) / o1[u]);
-                temp = temp > 0.0 ? temp : 0.0;
-                const double qq = o1[u] / o2[u];
-                const double temp2 = temp * qq * qq;
-                if (temp2 <= tol3z) {
-                    double sq = 0.0;
+                if ((t >> 6) == i) au = wave_bcast(x[u][i], t & 63);
+            if ((ln & 7) == u) ajc = au;
+        }
+        // norm downdate of the 8 columns, one column per lane (dlaqp2 rule)
+        bool need = false;
+        if (my_o1 != 0.0) {
+            double temp = 1.0 - (fabs(ajc) / my_o1) * (fabs(ajc) / my_o1);
+            temp = temp > 0.0 ? temp : 0.0;
+            const double qq = my_o1 / my_o2;
+            const double temp2 = temp * qq * qq;
+            if (temp2 <= tol3z) need = true;
+            else my_o1 = my_o1 * sqrt(temp);
+        }
+        unsigned nm = (unsigned)(__ballot(need && ln < 8) & 0xffull);
+        while (nm) {   // rare: recompute the partial norm of a column from its entries
+            const int u = __ffs((int)nm) - 1;
+            nm &= nm - 1;
+            double sq = 0.0;
+#pragma unroll
+            for (int uu = 0; uu < 8; ++uu)
+                if (uu == u) {
 #pragma unroll
                     for (int i = 0; i < RPL; ++i)
-                        if (ln + 64 * i > t) sq += x[u][i] * x[u][i];
-                    sq = wave_allsum(sq);
-                    o1[u] = (jb + t + 1 < kp) ? sqrt(sq) : 0.0;
-                    o2[u] = o1[u];
-                } else {
-                    o1[u] = o1[u] * sqrt(temp);
+                        if (ln + 64 * i > t) sq += x[uu][i] * x[uu][i];
                 }
+            sq = wave_allsum(sq);
+            if ((ln & 7) == u) {
+                my_o1 = (jb + t + 1 < kp) ? sqrt(sq) : 0.0;
+                my_o2 = my_o1;
             }
         }
 #pragma unroll
         for (int i = 0; i < RPL; ++i) v[i] = vn[i];
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 8; ++u) {
+        if (!((actmask >> u) & 1u)) continue;
         const int c = cbase + u;
-        if (!act[u]) continue;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             const int r = ln + 64 * i;
             if (r < rows) M[(jb + r) + (size_t)c * a.q.ldr] = x[u][i];
         }
-        if (c < n2 && ln == 0) {
-            vn1[c] = o1[u];
-            vn2[c] = o2[u];
-        }
+    }
+    if (ln < 8 && my_act && myc < n2) {
+        vn1[myc] = my_o1;
+        vn2[myc] = my_o2;
     }
 }
 

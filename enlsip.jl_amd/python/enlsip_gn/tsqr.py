@@ -1,0 +1,140 @@
+"""Row-sharded TSQR of one tall residual Jacobian across the GPUs of a node (config C4).
+
+One process per GPU under ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI).  Rank g holds
+rows ``[g*m/G, (g+1)*m/G)`` of ``J`` and ``rx``; the small constraint data are replicated.  There is
+exactly ONE exchange step on the path: an all-gather of the ``n2 x n2`` triangles (8*n2^2 bytes per
+rank, 8.4 MB at n2 = 1024) and of the ``n2``-vectors, plus a scalar all-reduce for ``||d||``.  xGMI
+is point-to-point (7 links per GPU), so the all-gather of G-1 messages uses all links at once
+and costs tens of microseconds against ~1 ms of local factorisation.
+
+The local and combine stages are the HIP library's ``enlsip_gn_tsqr_local_dev`` /
+``enlsip_gn_tsqr_combine_dev``; they are injectable only so that the exchange / stacking logic can be
+exercised with the ``gloo`` backend on machines without a GPU (tests/test_tsqr_host.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import _lib as L
+from .api import GNSolver, SQRT_EPS
+
+
+@dataclass
+class TSQRResult:
+    p: np.ndarray          # search direction (n)
+    dlead: np.ndarray      # leading n2 entries of F_J2.Q' d
+    d_norm: float          # ||d||_2 over all ranks
+    rankA: int
+    rankJ2: int
+    code: int
+    jpvtJ2: np.ndarray
+    n2: int
+
+
+def row_range(m: int, G: int, g: int):
+    """Rows of rank g: contiguous blocks, the first m % G ranks get one extra row."""
+    base, extra = divmod(m, G)
+    lo = g * base + min(g, extra)
+    return lo, lo + base + (1 if g < extra else 0)
+
+
+def hip_local_stage(solver: GNSolver, m_loc, n, t, dJ, ldj, drx, dAt, dcx, dR, dz, eps_rank):
+    """enlsip_gn_tsqr_local_dev on raw device pointers; returns (n2, tail_sq)."""
+    tail = C.c_double(0.0)
+    n2 = C.c_int64(0)
+    v = lambda x: C.c_void_p(x) if x else None
+    solver._chk(solver._lib.enlsip_gn_tsqr_local_dev(solver._h, m_loc, n, t, v(dJ), ldj, v(drx), v(dAt), max(n, 1),
+                                                     v(dcx), eps_rank, v(dR), v(dz), C.byref(tail), C.byref(n2)))
+    return int(n2.value), float(tail.value)
+
+
+def hip_combine_stage(solver: GNSolver, G, n, n2, dRstack, dzstack, eps_rank):
+    p = np.zeros(n)
+    dlead = np.zeros(n2)
+    jp = np.zeros(n2, dtype=np.int64)
+    ct = C.c_double(0.0)
+    info = L.Info()
+    v = lambda x: C.c_void_p(x) if x else None
+    solver._chk(solver._lib.enlsip_gn_tsqr_combine_dev(solver._h, G, n2, v(dRstack), v(dzstack), eps_rank,
+                                                       p.ctypes.data_as(C.c_void_p), dlead.ctypes.data_as(C.c_void_p),
+                                                       C.byref(ct), C.byref(info), jp.ctypes.data_as(C.c_void_p)))
+    return p, dlead, float(ct.value), info, jp
+
+
+def tsqr_solve(solver: Optional[GNSolver], J_loc, rx_loc, At, cx, eps_rank: float = SQRT_EPS, group=None,
+               local_stage: Callable = None, combine_stage: Callable = None) -> TSQRResult:
+    """Collective over ``group``.  ``J_loc``: torch tensor (n, m_loc) C-order == column-major
+    m_loc x n on this rank's device; ``rx_loc`` (m_loc); ``At`` (t, n) C-order == column-major n x t
+    (replicated); ``cx`` (t).  Every rank returns the same result."""
+    import torch
+    import torch.distributed as dist
+
+    G = dist.get_world_size(group) if dist.is_initialized() else 1
+    n, m_loc = J_loc.shape
+    t = 0 if At is None else At.shape[0]
+    dev = J_loc.device
+    R = torch.zeros((n * n,), dtype=torch.float64, device=dev)
+    z = torch.zeros((n,), dtype=torch.float64, device=dev)
+    if local_stage is None:
+        n2, tail = hip_local_stage(solver, m_loc, n, t, J_loc.data_ptr(), m_loc, rx_loc.data_ptr(),
+                                   At.data_ptr() if t else 0, cx.data_ptr() if t else 0, R.data_ptr(), z.data_ptr(),
+                                   eps_rank)
+    else:
+        n2, tail = local_stage(J_loc, rx_loc, At, cx, R, z, eps_rank)
+    # ---- the one exchange step --------------------------------------------------------------------
+    Rstack = torch.empty((G * n2 * n2,), dtype=torch.float64, device=dev)
+    zstack = torch.empty((G * n2,), dtype=torch.float64, device=dev)
+    tails = torch.tensor([tail], dtype=torch.float64, device=dev)
+    if G > 1:
+        dist.all_gather_into_tensor(Rstack, R[: n2 * n2].contiguous(), group=group)
+        dist.all_gather_into_tensor(zstack, z[:n2].contiguous(), group=group)
+        dist.all_reduce(tails, op=dist.ReduceOp.SUM, group=group)
+    else:
+        Rstack.copy_(R[: n2 * n2])
+        zstack.copy_(z[:n2])
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()      # the library runs on its own stream
+    if combine_stage is None:
+        p, dlead, ctail, info, jp = hip_combine_stage(solver, G, n, n2, Rstack.data_ptr(), zstack.data_ptr(), eps_rank)
+        rankA, rankJ2, code = int(info.rankA), int(info.rankJ2), int(info.code)
+    else:
+        p, dlead, ctail, rankA, rankJ2, code, jp = combine_stage(G, n, n2, Rstack, zstack, eps_rank)
+    d_norm = float(np.sqrt(float(tails.item()) + ctail + float(np.dot(dlead, dlead))))
+    return TSQRResult(p=p, dlead=dlead, d_norm=d_norm, rankA=rankA, rankJ2=rankJ2, code=code, jpvtJ2=jp, n2=n2)
+
+
+def tsqr_solve_shards(solver: GNSolver, J, rx, A_active, cx, G: int, eps_rank: float = SQRT_EPS) -> TSQRResult:
+    """Single-process rehearsal on ONE GPU: the G row blocks are factored one after the other on the
+    same handle and stacked exactly as the all-gather would (used by the GPU tests; the handle's
+    resident F_A / p1 come from the last local stage, identical on every 'rank')."""
+    import torch
+    m, n = J.shape
+    t = A_active.shape[0]
+    dev = torch.device("cuda", 0)
+    At = torch.tensor(np.ascontiguousarray(A_active), dtype=torch.float64, device=dev) if t else None
+    cxd = torch.tensor(cx, dtype=torch.float64, device=dev) if t else None
+    Rs, zs, tail_total, n2 = [], [], 0.0, None
+    for g in range(G):
+        lo, hi = row_range(m, G, g)
+        Jl = torch.tensor(np.ascontiguousarray(J[lo:hi].T), dtype=torch.float64, device=dev)
+        rl = torch.tensor(rx[lo:hi], dtype=torch.float64, device=dev)
+        R = torch.zeros((n * n,), dtype=torch.float64, device=dev)
+        z = torch.zeros((n,), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        n2, tail = hip_local_stage(solver, hi - lo, n, t, Jl.data_ptr(), hi - lo, rl.data_ptr(),
+                                   At.data_ptr() if t else 0, cxd.data_ptr() if t else 0, R.data_ptr(), z.data_ptr(),
+                                   eps_rank)
+        Rs.append(R[: n2 * n2].clone())
+        zs.append(z[:n2].clone())
+        tail_total += tail
+    Rstack = torch.cat(Rs).contiguous()
+    zstack = torch.cat(zs).contiguous()
+    torch.cuda.synchronize()
+    p, dlead, ctail, info, jp = hip_combine_stage(solver, G, n, n2, Rstack.data_ptr(), zstack.data_ptr(), eps_rank)
+    d_norm = float(np.sqrt(tail_total + ctail + float(np.dot(dlead, dlead))))
+    return TSQRResult(p=p, dlead=dlead, d_norm=d_norm, rankA=int(info.rankA), rankJ2=int(info.rankJ2),
+                      code=int(info.code), jpvtJ2=jp, n2=n2)

@@ -148,22 +148,38 @@ int enlsip_gn_get_JQ1(enlsip_gn_handle h, int64_t prob, double* out, int64_t ld)
 int enlsip_gn_resolve(enlsip_gn_handle h, int64_t prob, int64_t dimA, int64_t dimJ2, int64_t code,
                       double* p, double* b, double* d);
 
-/* ---- row-sharded TSQR building blocks (multi-GPU config C4; see INTEGRATION.md §4) ----------
- * Local stage on this GPU's row block of [J2 | d_temp] (t = 0: J2 = J, d_temp = -rx):
- * unpivoted blocked QR, leaves Rloc (n x n upper, packed column-major with ld = n) and
- * zloc = (Q_loc' d)[1:n] in DEVICE buffers and returns ||(Q_loc' d)[n+1:]||^2 in tail_sq (host).
+/* ---- row-sharded TSQR building blocks (multi-GPU config C4; see INTEGRATION.md §5) ----------
+ * One tall residual Jacobian whose ROWS are sharded over G GPUs; the (small) constraint data
+ * At, cx are replicated.  Same mathematics as enlsip_gn_solve:  F_A, rankA, F_L11, p1 are
+ * computed redundantly on every rank (bitwise identical), J*Q1 and d_temp = -J1 p1 - rx are
+ * row-local, the unpivoted QR of [J2 | d_temp] is done on the local rows, and only the
+ * n2 x n2 triangles travel.
+ *
+ * Local stage (device buffers in, device buffers out):
+ *   dRloc  n2 x n2 upper-triangular factor of the local rows, column-major, PACKED (ld = n2), so the
+ *          first n2*n2 doubles can be all-gathered as they are; the caller provides n*n doubles
+ *          (n2 = n - rankA <= n is only known afterwards and is returned in *n2_out)
+ *   dzloc  (Q_loc' d_loc)[1:n2]             (n doubles provided)
+ *   tail_sq  ||(Q_loc' d_loc)[n2+1:]||^2    (host)
  */
-int enlsip_gn_tsqr_local_dev(enlsip_gn_handle h, int64_t m_loc, int64_t n,
+int enlsip_gn_tsqr_local_dev(enlsip_gn_handle h, int64_t m_loc, int64_t n, int64_t t,
                              const double* dJ, int64_t ldj, const double* drx,
-                             double* dRloc, double* dzloc, double* tail_sq);
+                             const double* dAt, int64_t ldat, const double* dcx, double eps_rank,
+                             double* dRloc, double* dzloc, double* tail_sq, int64_t* n2_out);
 /*
- * Combine stage, run redundantly on every rank after the all-gather: stacked (G*n) x n matrix of
- * the G upper-triangular Rloc blocks and the stacked zloc (DEVICE), -> p (n), the leading n
- * entries of d, rankJ2, jpvtJ2 (HOST outputs).
+ * Combine stage, run redundantly on every rank after the all-gather (RCCL) of the G local results:
+ *   dRstack  G blocks of n2 x n2 (each column-major, ld = n2, i.e. the dRloc buffers packed to n2*n2)
+ *   dzstack  G blocks of n2
+ * Factors the stacked (G*n2) x n2 matrix (unpivoted CAQR, then the pivoted QR of its R — the same
+ * plan as a single-GPU solve), solves, and applies Q1 of the handle's resident F_A (from the
+ * local stage on the SAME handle).  HOST outputs: p (n), dlead (n2) = leading entries of
+ * F_J2.Q' d, comb_tail_sq = squared norm of the remaining entries of the stacked rhs (add the
+ * ranks' tail_sq for ||d||^2), info, jpvtJ2 (n2).
  */
-int enlsip_gn_tsqr_combine_dev(enlsip_gn_handle h, int64_t G, int64_t n,
+int enlsip_gn_tsqr_combine_dev(enlsip_gn_handle h, int64_t G, int64_t n2,
                                const double* dRstack, const double* dzstack, double eps_rank,
-                               double* p, double* dlead, enlsip_gn_info* info, int64_t* jpvtJ2);
+                               double* p, double* dlead, double* comb_tail_sq,
+                               enlsip_gn_info* info, int64_t* jpvtJ2);
 
 /* ---- instrumentation: HIP-event time (ms) of the stages of the last solve ------------------ */
 enum {

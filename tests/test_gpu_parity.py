@@ -192,3 +192,19 @@ def test_linearity_in_rhs(solver):
     p3 = solver.solve(J, rx2, A, np.zeros(t)).p
     p4 = solver.solve(J, rx + rx2, A, cx).p
     assert rel(p4, p1 + p3) <= 1e-11
+
+
+@pytest.mark.parametrize("m,n,t,G", [(4000, 64, 0, 4), (3001, 48, 5, 3), (20000, 96, 0, 8), (300, 40, 6, 2)])
+def test_tsqr_row_shards_match_single_solve(m, n, t, G, solver):
+    """Row-sharded TSQR (config C4 structure) rehearsed on one GPU: G local stages + combine must
+    reproduce the oracle's p, ranks, pivots and ||d|| of the unsharded problem."""
+    from enlsip_gn.tsqr import tsqr_solve_shards
+    J, rx, A, cx = synth.make_problem(900 + m, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    res = tsqr_solve_shards(solver, J, rx, A, cx, G)
+    assert res.n2 == n - ref.rankA and res.rankA == ref.rankA and res.rankJ2 == ref.rankJ2
+    assert rel(res.p, ref.p) <= TOL_P
+    assert abs(res.d_norm - np.linalg.norm(ref.d)) <= 1e-11 * np.linalg.norm(ref.d)
+    assert np.array_equal(res.jpvtJ2, ref.jpvtJ2)
+    r = ref.rankJ2
+    assert np.abs(np.abs(res.dlead[:r]) - np.abs(ref.d[:r])).max() <= 1e-10 * max(np.abs(ref.d).max(), 1.0)
