@@ -208,3 +208,75 @@ def test_tsqr_row_shards_match_single_solve(m, n, t, G, solver):
     assert np.array_equal(res.jpvtJ2, ref.jpvtJ2)
     r = ref.rankJ2
     assert np.abs(np.abs(res.dlead[:r]) - np.abs(ref.d[:r])).max() <= 1e-10 * max(np.abs(ref.d).max(), 1.0)
+
+
+def _ws_case(kind):
+    """(J, rx, A_all, cx_all, q, active ids 1-based) for update_working_set comparisons."""
+    if kind == "hs65":
+        J, rx, A, cx, active = hs65_start()
+        return J, rx, A, cx, 0, active
+    m, n, l = 200, 12, 7
+    J, rx, A, cx = synth.make_problem(4242, m, n, l)
+    if kind == "eq_only":
+        return J, rx, A, cx, l, np.arange(1, l + 1)
+    # 2 equalities + 3 active inequalities out of 5
+    return J, rx, A, cx, 2, np.array([1, 2, 3, 5, 6])
+
+
+@pytest.mark.parametrize("kind", ["hs65", "eq_only", "mixed"])
+@pytest.mark.parametrize("scaling", [False, True])
+def test_update_working_set_mirror(kind, scaling, solver):
+    """Host mirror of update_working_set over the HIP library vs the oracle's restatement of
+    src/enlsip_functions.jl:686-795: same direction, same working-set mutations, same multipliers."""
+    from enlsip_gn import working_set as ws
+    J, rx, A, cx, q, active = _ws_case(kind)
+    m, n = J.shape
+    l = A.shape[0]
+
+    def build(mod):
+        W = mod.new_working_set(q, l) if hasattr(mod, "new_working_set") else mod.WorkingSet.create(q, l)
+        add = (lambda s: mod.add_constraint(W, s)) if hasattr(mod, "add_constraint") else W.add_constraint
+        for idx in active:
+            if idx > q:
+                add(int(np.where(W.inactive == idx)[0][0]) + 1)
+        C = mod.Constraint(cx[active - 1].copy(), A[active - 1].copy(), scaling, np.zeros(len(active)))
+        return W, C
+
+    Wr, Cr = build(go)
+    go.evaluate_scaling(Cr)
+    itr = go.IterationRecord()
+    pr = np.zeros(n)
+    nref = []
+    go.update_working_set(Wr, rx, A, Cr, J.T @ rx, J, pr, itr, go.SQRT_EPS, solve=lambda: nref.append(1))
+
+    Wg, Cg = build(ws)
+    # same scaling step as the reference performs before the call (src/enlsip_functions.jl:2696)
+    Cg.A, Cg.cx, Cg.diag_scale = Cr_scaled_inputs(A, cx, active, scaling)
+    itg = ws.IterationRecord()
+    pg = np.zeros(n)
+    ngpu = []
+    F_A, F_L11, F_J2 = ws.update_working_set(solver, Wg, rx, A, Cg, J.T @ rx, J, pg, itg, go.SQRT_EPS,
+                                             on_solve=lambda: ngpu.append(1))
+    assert Wg.t == Wr.t and np.array_equal(Wg.active, Wr.active) and np.array_equal(Wg.inactive, Wr.inactive)
+    assert itg.delete == itr.delete and itg.index_del == itr.index_del
+    assert (itg.rankA, itg.rankJ2) == (itr.rankA, itr.rankJ2)
+    assert rel(pg, pr) <= 1e-10
+    np.testing.assert_allclose(itg.lam, itr.lam, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(itr.lam).max()))
+    assert len(ngpu) in (len(nref), len(nref) + 1)       # the device form pays one extra solve only when s != 0
+    assert F_J2.R.shape[1] == n - itg.rankA
+
+
+def Cr_scaled_inputs(A, cx, active, scaling):
+    """evaluate_scaling! (src/structures.jl:160-178) applied to fresh copies."""
+    Aa, ca = A[active - 1].copy(), cx[active - 1].copy()
+    diag = np.zeros(len(active))
+    for i in range(len(active)):
+        row = float(np.linalg.norm(Aa[i]))
+        diag[i] = row
+        if scaling:
+            if abs(row) < np.finfo(float).eps:
+                row = 1.0
+            Aa[i] /= row
+            ca[i] /= row
+            diag[i] = 1.0 / row
+    return Aa, ca, diag
