@@ -33,11 +33,12 @@ julia ^1.8).  Julia is not installed in the build container, so the reference ca
 run, and the reference's own tests hold NO numeric assertion on this path.
 The only known answer the reference publishes is the HS65 solution / objective in
 docs/src/tutorial.md:126-128; ``oracle/enlsip_outer.py`` (host restatement of the outer
-loop) is checked against it in tests/test_hs65_known_answer.py.  For the subproblem
-boundary itself the status is therefore:
+loop) reproduces it with this file as its subproblem (tests/test_hs65_known_answer.py:
+objective within 1e-10, solution within 5e-7 — and, like the reference, NOT within
+sqrt(eps), docs/src/tutorial.md:201-211).  Status:
 
-    parity unpinned at the subproblem boundary (no reference vectors exist);
-    pinned end-to-end only through the HS65 known answer.
+    pinned end to end on the reference's HS65 known answer;
+    no reference vectors exist at the subproblem boundary itself (unpinned there).
 
 Conventions: column-major semantics are irrelevant in NumPy, but every permutation
 returned is the **1-based LAPACK jpvt** exactly as Julia's ``F.p``.
