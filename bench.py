@@ -49,6 +49,7 @@ def main() -> int:
     ap.add_argument("--t", type=int, default=64)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline sampling (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tile-rows", type=int, default=0, help="CAQR tile rows (0 = library default 512; 256)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,9 +87,9 @@ def main() -> int:
     jJ = torch.empty((B, n), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
-    solver = GNSolver(device=local_rank)
+    solver = GNSolver(device=local_rank, tile_rows=args.tile_rows)
     S = max(1, min(args.streams, B))
-    solvers = [solver] + [GNSolver(device=local_rank) for _ in range(S - 1)]
+    solvers = [solver] + [GNSolver(device=local_rank, tile_rows=args.tile_rows) for _ in range(S - 1)]
     bounds = [(B * i) // S for i in range(S + 1)]
 
     def part(i):

@@ -58,6 +58,9 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     P.RPL = h->tile_rows / 64;
     P.F = 2 * P.RPL;
     P.ldw = (int)rup(std::max<long long>(m, 1), 32);
+    // a leading dimension that is a multiple of 4 KB puts the same row range of every column on the
+    // same few HBM channels (measured: 4x slower edge tiles at ldw = 4096): skew it by one 256-B block
+    if (P.ldw % 512 == 0) P.ldw += 32;
     const long long kpmax = std::min(m, n);
     P.ldr = (int)rup(std::max<long long>(kpmax, 1), 8);
     P.npan_max = (int)((kpmax + PB - 1) / PB);
@@ -246,7 +249,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
                     e1 = h->upd_ev[h->upd_used++];
                     GN_HIP(hipEventRecord(e0, h->stream));
                 }
-                if (use_mfma && lvl0) launch_update_mfma(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
+                if (use_mfma) launch_update_mfma(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
                 else launch_update_refl(h, a, L.groups, ntrail);
                 if (e1) {
                     GN_HIP(hipEventRecord(e1, h->stream));

@@ -45,7 +45,7 @@ struct CaqrArgs {
 // panel factorisation of one group (tile or tree node)
 // ---------------------------------------------------------------------------------------------
 template <int RPL>
-__global__ __launch_bounds__(256) void k_caqr_factor(CaqrArgs a) {
+__global__ __launch_bounds__(256, 2) void k_caqr_factor(CaqrArgs a) {
     __shared__ double vsh[2][64 * RPL];
     __shared__ double taush[PB];
     __shared__ double gsh[PB][PB + 1];
@@ -158,18 +158,17 @@ __global__ __launch_bounds__(256) void k_caqr_factor(CaqrArgs a) {
     if (w == 0) {
         double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
         if (ln < PB) {
-            double trow[PB];
-#pragma unroll
+            // row ln of T lives in LDS (vsh is free now): no register array, so the kernel keeps its
+            // register budget for the tile and two workgroups fit a CU
+            double* trow = &vsh[0][0] + ln * (PB + 1);
             for (int j = 0; j < PB; ++j) {
                 const double tj = taush[j];
                 double s = 0.0;
-#pragma unroll
-                for (int l = 0; l < j; ++l)
-                    if (l >= ln) s += trow[l] * gsh[l][j];
-                trow[j] = (ln == j) ? tj : ((ln < j) ? -tj * s : 0.0);
+                for (int l = ln; l < j; ++l) s += trow[l] * gsh[l][j];
+                const double tv = (ln == j) ? tj : ((ln < j) ? -tj * s : 0.0);
+                trow[j] = tv;
+                T[ln + j * PB] = tv;
             }
-#pragma unroll
-            for (int j = 0; j < PB; ++j) T[ln + j * PB] = trow[j];
         }
     }
 }

@@ -5,6 +5,8 @@
 //     W2 = -W1 T        (64 x 64)(64 x 64)    phase 2
 //     Jrb += W2 V'      (64 x 64)(64 x n)     phase 3, output streamed in 32-column chunks
 // One workgroup owns 64 rows; J is read twice (HBM, then L2) and the workspace written once.
+// Both streaming loops are software-pipelined: the global loads of chunk c+1 are issued before
+// the MFMAs of chunk c and only waited for at the next LDS write.
 //
 // Fragment maps (cdna_hip_programming.md §3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
 // D[i = (l>>4) + 4 r][j = l&15].  LDS leading dimensions are chosen so the two 16-lane groups of
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(256, 2) void k_jq1_mfma(JQ1Args a) {
     const int rankA = a.state[prob].rankA;
     const int tid = threadIdx.x, ln = lane_id(), w = wave_id();
     const int lr = ln & 15, lq = ln >> 4;
-    const int srow = tid & 63, scg = tid >> 6;   // staging geometry: 64 rows x 4 column groups
+    const int srow = tid & 63, scg = tid >> 6;   // J staging: 64 rows x 4 column groups
+    const int vkk = tid & 31, vcg = tid >> 5;    // V staging: 32 rows of V x 8 reflector groups
 
     if (row0 >= m) {  // pure padding rows
         for (int e = tid; e < QM_RB * (n + 1); e += 256) {
@@ -71,28 +74,45 @@ __global__ __launch_bounds__(256, 2) void k_jq1_mfma(JQ1Args a) {
         const long long lds_src = (b == 0) ? a.ldj : ldw;
         const int rows_src = (b == 0) ? m : ldw;
         const bool last = (b == nblk - 1);
+        const int kfirst = (c0 / QM_KC) * QM_KC;          // V_b is zero above row c0
+        auto load_j = [&](int k0, double* jr) {
+            const int row = row0 + srow;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int col = k0 + scg + 4 * u;
+                jr[u] = (col < n && row < rows_src) ? src[row + (size_t)col * lds_src] : 0.0;
+            }
+        };
+        auto load_v = [&](int k0, double* vr) {
+            const int gr = k0 + vkk;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = vcg + 8 * u;
+                const int gc = c0 + c;
+                double v = 0.0;
+                if (c < kb && gr < n) {
+                    const double x = FA[gr + (size_t)gc * n];
+                    v = (gr > gc) ? x : (gr == gc ? 1.0 : 0.0);
+                }
+                vr[u] = v;
+            }
+        };
         // ---- phase 1: W1 = Jrb * V_b  (wave w: row tile w, 4 column tiles) ---------------------
         mfma_d4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
-        for (int k0 = (c0 / QM_KC) * QM_KC; k0 < n; k0 += QM_KC) {   // V_b is zero above row c0
+        double jreg[8], vreg[8];
+        load_j(kfirst, jreg);
+        load_v(kfirst, vreg);
+        for (int k0 = kfirst; k0 < n; k0 += QM_KC) {
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int kk = scg + 4 * u;            // column of J within the chunk
-                const int col = k0 + kk, row = row0 + srow;
-                Jl[kk * QM_LDJ + srow] = (col < n && row < rows_src) ? src[row + (size_t)col * lds_src] : 0.0;
-            }
-            {
-                const int kk = tid & 31, cg = tid >> 5;   // 32 rows of V x 8 reflector groups
+            for (int u = 0; u < 8; ++u) Jl[(scg + 4 * u) * QM_LDJ + srow] = jreg[u];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = cg + 8 * u;
-                    const int gr = k0 + kk, gc = c0 + c;
-                    double v = 0.0;
-                    if (c < kb && gr < n) v = (gr > gc) ? FA[gr + (size_t)gc * n] : (gr == gc ? 1.0 : 0.0);
-                    Vl[c * QM_LDV + kk] = v;
-                }
+            for (int u = 0; u < 8; ++u) Vl[(vcg + 8 * u) * QM_LDV + vkk] = vreg[u];
+            if (k0 + QM_KC < n) {
+                load_j(k0 + QM_KC, jreg);
+                load_v(k0 + QM_KC, vreg);
             }
             __syncthreads();
 #pragma unroll
@@ -140,22 +160,9 @@ __global__ __launch_bounds__(256, 2) void k_jq1_mfma(JQ1Args a) {
             for (int r = 0; r < 4; ++r) Wl[(16 * ct + lr) * QM_LDJ + 16 * w + lq + 4 * r] = -acc[ct][r];
         // ---- phase 3: out chunk = J chunk + W2n * V_b'   (D[i = col][j = row]) ------------------------
         double dpart = 0.0;
-        for (int k0 = (c0 / QM_KC) * QM_KC; k0 < n; k0 += QM_KC) {
-            __syncthreads();
-            {
-                const int kk = tid & 31, cg = tid >> 5;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = cg + 8 * u;
-                    const int gr = k0 + kk, gc = c0 + c;
-                    double v = 0.0;
-                    if (c < kb && gr < n) v = (gr > gc) ? FA[gr + (size_t)gc * n] : (gr == gc ? 1.0 : 0.0);
-                    Vl[c * QM_LDV + kk] = v;
-                }
-            }
-            // C fragments straight from global: o[it][r] = J[row0 + 16 w + lr][k0 + 16 it + lq + 4 r]
-            mfma_d4 o[2];
-            const int row = row0 + 16 * w + lr;
+        const int row = row0 + 16 * w + lr;
+        auto load_o = [&](int k0, mfma_d4* o) {
+            // C fragments straight from global: o[it][r] = J[row][k0 + 16 it + lq + 4 r]
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -163,6 +170,18 @@ __global__ __launch_bounds__(256, 2) void k_jq1_mfma(JQ1Args a) {
                     const int col = k0 + 16 * it + lq + 4 * r;
                     o[it][r] = (col < n && row < rows_src) ? src[row + (size_t)col * lds_src] : 0.0;
                 }
+        };
+        mfma_d4 o[2], onext[2];
+        load_v(kfirst, vreg);
+        load_o(kfirst, o);
+        for (int k0 = kfirst; k0 < n; k0 += QM_KC) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Vl[(vcg + 8 * u) * QM_LDV + vkk] = vreg[u];
+            if (k0 + QM_KC < n) {
+                load_v(k0 + QM_KC, vreg);
+                load_o(k0 + QM_KC, onext);
+            }
             __syncthreads();
 #pragma unroll
             for (int ks = 0; ks < KBLK / 4; ++ks) {
@@ -184,17 +203,12 @@ __global__ __launch_bounds__(256, 2) void k_jq1_mfma(JQ1Args a) {
                         if (last && col < rankA) dpart += o[it][r] * p1[col];
                     }
                 }
-        }
-        // columns left of the block's first chunk are untouched by this block
-        if (b == 0) {
-            const int kstart = (c0 / QM_KC) * QM_KC;   // 0 for block 0
-            (void)kstart;
+            o[0] = onext[0];
+            o[1] = onext[1];
         }
         if (last) {
-            // columns < first chunk of the last block still contribute to d (blocks > 0 only)
-            const int kstart = (c0 / QM_KC) * QM_KC;
-            const int row = row0 + 16 * w + lr;
-            for (int col = lq; col < kstart && col < rankA; col += 4)
+            // columns left of the last block's first chunk still contribute to d (blocks > 0 only)
+            for (int col = lq; col < kfirst && col < rankA; col += 4)
                 if (row < ldw) dpart += W[row + (size_t)col * ldw] * p1[col];
             dpart += __shfl_xor(dpart, 16, WAVE);
             dpart += __shfl_xor(dpart, 32, WAVE);

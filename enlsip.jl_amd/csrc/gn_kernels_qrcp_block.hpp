@@ -396,19 +396,26 @@ __global__ __launch_bounds__(256) void k_sb_update(SbArgs a) {
             for (int i = 0; i < RPL; ++i) dot[u] += x[u][i] * v[i];
         }
         wave_allsum8(dot, ds);
-        double ajc = 0.0;   // entry of row jb + t of "my" column: local row t lives in lane t & 63, register t >> 6
+        if (tj != 0.0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (tj != 0.0) {
+            for (int u = 0; u < 8; ++u) {
                 const double wd = tj * ds[u];
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) x[u][i] -= wd * v[i];
             }
-            double au = 0.0;
+        }
+        // entry of row jb + t of "my" column: local row t lives in lane t & 63 of register t >> 6
+        // (one wave-uniform branch selects the register, then 8 readlanes)
+        double ajc = 0.0;
 #pragma unroll
-            for (int i = 0; i < RPL; ++i)
-                if ((t >> 6) == i) au = wave_bcast(x[u][i], t & 63);
-            if ((ln & 7) == u) ajc = au;
+        for (int i = 0; i < RPL; ++i) {
+            if ((t >> 6) == i) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double au = wave_bcast(x[u][i], t & 63);
+                    if ((ln & 7) == u) ajc = au;
+                }
+            }
         }
         // norm downdate of the 8 columns, one column per lane (dlaqp2 rule)
         bool need = false;

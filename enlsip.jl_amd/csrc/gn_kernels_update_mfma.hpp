@@ -21,7 +21,13 @@ constexpr int UM_CB = 32;        // trailing columns per workgroup
 constexpr int UM_LD = 66;        // LDS leading dimension of a 64-row chunk (conflict-free)
 constexpr int UM_WLD = 33;
 
-template <int RPL>
+// TRI = false: level 0 (a tile of 64*RPL contiguous rows).  TRI = true: a tree node — the rows are
+// the top 32 rows of F lower-level groups (block q at row offset q*S), and V is the TSQR-stored
+// reflector block: identity in block 0, upper triangles in the blocks q >= 1.
+// FULL = true: interior workgroups only (full tile, full column block, full panel) — no predicates in
+// the address / load code; FULL = false: the remaining edge workgroups.  Both are launched over the
+// same grid and a workgroup of the other kind exits at once.
+template <int RPL, bool TRI, bool FULL, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
     __shared__ __attribute__((aligned(16))) double Vl[PB * UM_LD];        // V chunk  [col][row]
     __shared__ __attribute__((aligned(16))) double Cl[UM_CB * UM_LD];     // C chunk  [col][row]
@@ -43,10 +49,18 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
     const double* Wm = a.W + prob * a.sW;
     double* C = a.W + prob * a.sW + (size_t)(st.rankA + first) * a.ldw;
     const double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
-    const long long tile_row0 = (long long)r0 + (long long)g * (64 * RPL);
+    // row of tile slot s (block q = s >> 5 of the group, row-in-block s & 31)
+    const long long gblk0 = (long long)g * a.F;
+    const long long tile_row0 = (long long)r0 + gblk0 * 32;          // level 0: contiguous rows
+    auto rowof = [&](int s) -> long long {
+        if (!TRI) return tile_row0 + s;
+        return (long long)r0 + (gblk0 + (s >> 5)) * a.S + (s & 31);
+    };
     // rows of this tile that exist: blocks g*F .. < nblocks, 32 rows each
     const long long blocks_here = (long long)a.nblocks - (long long)g * a.F;
     const int rows_valid = (int)((blocks_here < a.F ? blocks_here : a.F) * 32);
+    const bool is_full = (rows_valid == 64 * RPL) && (ncols - cb0 >= UM_CB) && (bw == PB);
+    if (SPLIT && is_full != FULL) return;   // SPLIT: interior and edge workgroups in separate launches
 
     // T into LDS: Tl[l * 33 + i] = T[l][i]
     for (int e = tid; e < PB * PB; e += 256) {
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = cb0 + 16 * ct + lq + 4 * r;
-                creg[ch][ct][r] = (c < ncols && rloc < rows_valid) ? C[tile_row0 + rloc + (size_t)c * a.ldw] : 0.0;
+                creg[ch][ct][r] = (FULL || (c < ncols && rloc < rows_valid)) ? C[rowof(rloc) + (size_t)c * a.ldw] : 0.0;
             }
     }
 
@@ -87,9 +101,15 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
             const int j = vcg + 4 * u;
             const int s = 64 * ch + vrow;
             double v = 0.0;
-            if (j < bw && s < rows_valid) {
-                if (s > j) v = Wm[tile_row0 + s + (size_t)(col0 + j) * a.ldw];
-                else if (s == j) v = 1.0;
+            if (FULL || (j < bw && s < rows_valid)) {
+                if (!TRI) {
+                    if (s > j) v = Wm[rowof(s) + (size_t)(col0 + j) * a.ldw];
+                    else if (s == j) v = 1.0;
+                } else {
+                    const int rb = s & 31;
+                    if (s < 32) v = (rb == j) ? 1.0 : 0.0;
+                    else if (rb <= j) v = Wm[rowof(s) + (size_t)(col0 + j) * a.ldw];
+                }
             }
             vr[u] = v;
         }
@@ -185,15 +205,22 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_mfma(CaqrArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = cb0 + 16 * ct + lq + 4 * r;
-                if (c < ncols && rloc < rows_valid) C[tile_row0 + rloc + (size_t)c * a.ldw] = creg[ch][ct][r];
+                if (FULL || (c < ncols && rloc < rows_valid)) C[rowof(rloc) + (size_t)c * a.ldw] = creg[ch][ct][r];
             }
     }
 }
 
 inline void launch_update_mfma(int RPL, const CaqrArgs& a, int groups, int ncols, int batch, hipStream_t s) {
     dim3 grid(groups, (ncols + UM_CB - 1) / UM_CB, batch);
-    if (RPL == 8) hipLaunchKernelGGL(k_caqr_update_mfma<8>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_caqr_update_mfma<4>, grid, dim3(256), 0, s, a);
+    if (a.level == 0) {
+        // (a split into a predicate-free interior launch + an edge launch was measured SLOWER on MI355X:
+        // the interior kernel gained nothing and all edge tiles share blockIdx.x, i.e. one XCD)
+        if (RPL == 8) hipLaunchKernelGGL((k_caqr_update_mfma<8, false, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_caqr_update_mfma<4, false, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (RPL == 8) hipLaunchKernelGGL((k_caqr_update_mfma<8, true, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_caqr_update_mfma<4, true, false>), grid, dim3(256), 0, s, a);
+    }
 }
 
 }  // namespace gn
