@@ -14,7 +14,7 @@ steps (barrier + synchronize on both sides, MAX over ranks).  Ranks shard indepe
 subproblems: no collective on the data path (weak scaling).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = level-0 CAQR trailing update (k_caqr_update_mfma): algorithmic
+  roofline      dominant kernel = level-0 CAQR trailing update (k_caqr_update_v4): algorithmic
                 bytes 8(2 m_k n_k + m_k b + b^2) per launch / launch time measured
                 with HIP events on the library's stream (enlsip_gn_get_update_stats).
   cpu_baseline  the same LAPACK call sequence the Julia reference dispatches to (scipy/OpenBLAS
@@ -163,7 +163,7 @@ def main() -> int:
         if launches:
             per_launch_bytes = bytes_total / launches
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_caqr_update_mfma (level-0 trailing update)",
+            roofline = {"bound": "hbm", "kernel": "k_caqr_update_v4 (level-0 trailing update)",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 5),

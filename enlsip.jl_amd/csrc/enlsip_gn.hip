@@ -14,7 +14,7 @@
 #include "gn_kernels_final.hpp"
 #include "gn_kernels_q1.hpp"
 #include "gn_kernels_q1_mfma.hpp"
-#include "gn_kernels_update_mfma.hpp"
+#include "gn_kernels_update_v4.hpp"
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_qrcp_dist.hpp"
 #include "gn_kernels_qrcp_persist.hpp"
@@ -67,7 +67,7 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     long long running = 0;
     P.panels.resize(P.npan_max);
     for (int k = 0; k < P.npan_max; ++k) {
-        int nb = P.ldw / 32 - k;  // 32-row blocks from row 32k to ldw
+        int nb = (int)(rup(std::max<long long>(m, 1), 32) / 32) - k;  // 32-row blocks from row 32k to the padded m (NOT ldw: the skew rows are never touched)
         long long S = 32;
         int level = 0;
         while (true) {
@@ -91,7 +91,8 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     P.sFA = pad(n * t); P.sTauA = pad(P.kA); P.sJA = pad(t);
     P.sFL = pad(t * P.kA); P.sTauL = pad(P.kA); P.sJL = pad(P.kA);
     P.sTA = pad(nblkA * KBLK * KBLK); P.sP1 = pad(t); P.sB = pad(t);
-    P.sW = pad((long long)P.ldw * (n + 1));
+    // 32 spare columns per problem: the trailing-update kernel reads (and discards) whole 32-column blocks
+    P.sW = pad((long long)P.ldw * (n + 1 + 32));
     P.sT = pad(P.nTblocks * PB * PB);
     P.sRt = pad((long long)P.ldr * (n + 1));
     P.sTauJ = pad(kpmax); P.sJJ = pad(n); P.sZ = pad(kpmax);
@@ -150,7 +151,7 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
 
 static int check_limits(enlsip_gn_handle h, long long batch, long long m, long long n, long long t) {
     if (batch < 1) { h->err = "batch must be >= 1"; return -2; }
-    if (m < 1 || m > (1LL << 30)) { h->err = "m out of range"; return -3; }
+    if (m < 1 || m > (1LL << 27)) { h->err = "m out of range (1 .. 2^27: 32-bit lane offsets in the update kernel)"; return -3; }
     if (n < 1 || n > 1024) { h->err = "n must be in 1..1024 in this build"; return -4; }
     if (t < 0 || t > 1024) { h->err = "t must be in 0..1024 in this build"; return -5; }
     return 0;
@@ -249,11 +250,11 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
                     e1 = h->upd_ev[h->upd_used++];
                     GN_HIP(hipEventRecord(e0, h->stream));
                 }
-                if (use_mfma) launch_update_mfma(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
+                if (use_mfma) launch_update_v4(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
                 else launch_update_refl(h, a, L.groups, ntrail);
                 if (e1) {
                     GN_HIP(hipEventRecord(e1, h->stream));
-                    const double mk = (double)(P.ldw - k * PB);
+                    const double mk = (double)(rup(std::max<long long>(P.m, 1), 32) - k * PB);
                     h->upd_bytes += (double)P.batch * 8.0 * (2.0 * mk * ntrail + mk * PB + PB * PB);
                 }
             }

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_caqr_factor(CaqrArgs a) {
 // ---------------------------------------------------------------------------------------------
 // trailing update, reference form: the group's reflectors are applied one after the other
 // (dorm2r), columns in registers.  Used for tree levels, for applying Q'/Q to vectors, and as the
-// A/B partner of the MFMA kernel (gn_kernels_update_mfma.hpp) on level 0.
+// A/B partner of the MFMA kernel (gn_kernels_update_v4.hpp).
 // ---------------------------------------------------------------------------------------------
 template <int RPL>
 __global__ __launch_bounds__(256) void k_caqr_update_refl(CaqrArgs a) {

@@ -14,7 +14,7 @@
 // 34 / 66 for images read with lanes along columns.
 #pragma once
 #include "gn_kernels_q1.hpp"
-#include "gn_kernels_update_mfma.hpp"
+#include "gn_kernels_update_v4.hpp"
 
 namespace gn {
 
