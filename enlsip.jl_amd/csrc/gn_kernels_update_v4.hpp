@@ -67,7 +67,9 @@ struct V4Ctx {
 // CFULL = true : 32 valid columns and a full panel (bw = 32): no validity selects.
 // NGW   = number of 32-row units this wave owns (0..RPL/2), a compile-time constant so that every path
 //         is straight-line code.
-template <int RPL, bool TRI, bool CFULL, int NGW>
+// NCT   = 16-column tiles in use: 1 for a last block of <= 16 columns (the carried right-hand side makes
+//         the column count 32 k + 1, so every panel ends with such a block).
+template <int RPL, bool TRI, bool CFULL, int NGW, int NCT>
 __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*stage)[V4_STAGE], double* W2l) {
     const int ln = lane_id();
     const int lr = ln & 15, lq = ln >> 4;
@@ -95,7 +97,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     v4_d2 cp[NGW > 0 ? NGW : 1][2][4];
     auto issue_c = [&](int g) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (V4_ABLATE == 3 || V4_ABLATE == 5) cp[g][ct][r] = (v4_d2){(double)(g + r), (double)ct};
@@ -105,7 +107,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     auto finish_c = [&](int g) {
         if (CFULL) return;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = c.cb0 + 16 * ct + 4 * r + lq < c.ncols;
@@ -169,7 +171,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) *(v4_d2*)&Vs[(4 * ks + lq) * V4_LD + 2 * lr] = vp[ks >> 2][ks & 3];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) *(v4_d2*)&Cs[(16 * ct + lq + 4 * r) * V4_LD + 2 * lr] = cp[g][ct][r];
             // next operands: V one unit ahead (same registers), C two units ahead (its own registers)
@@ -192,12 +194,12 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
 #pragma unroll
                     for (int it = 0; it < 2; ++it) av[it][k4] = Vs[(16 * it + lr) * V4_LD + kr];
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) bv[ct][k4] = Cs[(16 * ct + lr) * V4_LD + kr];
+                    for (int ct = 0; ct < NCT; ++ct) bv[ct][k4] = Cs[(16 * ct + lr) * V4_LD + kr];
                 }
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
+                    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                         for (int k4 = 0; k4 < 4; ++k4) {
                             if (V4_ABLATE == 4) acc[it][ct][k4] += av[it][k4] + bv[ct][k4];
@@ -240,7 +242,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) fr[p][ct] = (v4_d4){cp[g][ct][0][p], cp[g][ct][1][p], cp[g][ct][2][p], cp[g][ct][3][p]};
+            for (int ct = 0; ct < NCT; ++ct) fr[p][ct] = (v4_d4){cp[g][ct][0][p], cp[g][ct][1][p], cp[g][ct][2][p], cp[g][ct][3][p]};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int u = 2 * g + h;                     // piece index; piece u + 1 is fetched while u is used
@@ -248,7 +250,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             __builtin_amdgcn_sched_barrier(0);
             finish_v(g, h, vb[u & 1]);
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 double a2[4];
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) a2[k4] = W2l[(16 * h + 4 * k4 + lq) * PB + 16 * ct + lr];   // A[i = col][k]
@@ -263,7 +265,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (V4_ABLATE == 3 || V4_ABLATE == 5) {
@@ -276,15 +278,15 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     }
 }
 
-template <int RPL, bool TRI, bool CFULL>
+template <int RPL, bool TRI, bool CFULL, int NCT>
 __device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, double (*stage)[V4_STAGE], double* W2l) {
     constexpr int NG = RPL / 2;
     // every variant executes exactly two workgroup barriers, so waves of one workgroup may take different ones
-    if (ngw >= NG) v4_body<RPL, TRI, CFULL, NG>(c, w, stage, W2l);
-    else if (NG > 3 && ngw == 3) v4_body<RPL, TRI, CFULL, (NG > 3 ? 3 : 0)>(c, w, stage, W2l);
-    else if (NG > 2 && ngw == 2) v4_body<RPL, TRI, CFULL, (NG > 2 ? 2 : 0)>(c, w, stage, W2l);
-    else if (NG > 1 && ngw == 1) v4_body<RPL, TRI, CFULL, (NG > 1 ? 1 : 0)>(c, w, stage, W2l);
-    else v4_body<RPL, TRI, CFULL, 0>(c, w, stage, W2l);
+    if (ngw >= NG) v4_body<RPL, TRI, CFULL, NG, NCT>(c, w, stage, W2l);
+    else if (NG > 3 && ngw == 3) v4_body<RPL, TRI, CFULL, (NG > 3 ? 3 : 0), NCT>(c, w, stage, W2l);
+    else if (NG > 2 && ngw == 2) v4_body<RPL, TRI, CFULL, (NG > 2 ? 2 : 0), NCT>(c, w, stage, W2l);
+    else if (NG > 1 && ngw == 1) v4_body<RPL, TRI, CFULL, (NG > 1 ? 1 : 0), NCT>(c, w, stage, W2l);
+    else v4_body<RPL, TRI, CFULL, 0, NCT>(c, w, stage, W2l);
 }
 
 template <int RPL, bool TRI>
@@ -317,8 +319,9 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4(CaqrArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
     const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;                     // units w, w + 4, ... < nvu
     const bool cfull = (c.ncols - c.cb0 >= 32) && (c.bw == PB);
-    if (cfull) v4_dispatch<RPL, TRI, true>(c, w, ngw, stage, W2l);
-    else v4_dispatch<RPL, TRI, false>(c, w, ngw, stage, W2l);
+    if (cfull) v4_dispatch<RPL, TRI, true, 2>(c, w, ngw, stage, W2l);
+    else if (c.ncols - c.cb0 <= 16) v4_dispatch<RPL, TRI, false, 1>(c, w, ngw, stage, W2l);
+    else v4_dispatch<RPL, TRI, false, 2>(c, w, ngw, stage, W2l);
 }
 
 inline void launch_update_v4(int RPL, const CaqrArgs& a, int groups, int ncols, int batch, hipStream_t s) {
