@@ -97,12 +97,13 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     P.sRt = pad((long long)P.ldr * (n + 1));
     P.sTauJ = pad(kpmax); P.sJJ = pad(n); P.sZ = pad(kpmax);
     P.sVec = pad((long long)P.ldw * 2);
-    P.sM = pad((long long)P.ldr * (n + 1)); P.sVb = pad((long long)P.ldr * std::max<long long>(kpmax, 1));
+    // + 33 columns: k_sb_update_blk reads whole 32-column / 32-row blocks past the last valid element
+    P.sM = pad((long long)P.ldr * (n + 1 + 33)); P.sVb = pad((long long)P.ldr * (std::max<long long>(kpmax, 1) + 33));
     P.sDiag = pad(kpmax); P.sVn = pad(n); P.sQI = pad(n);
     P.qdGmax = (int)((n + 1 + QD_CPW - 1) / QD_CPW);
     P.sCand = 2 * (long long)P.qdGmax;
     const long long per_dbl = P.sFA + P.sTauA + P.sFL + P.sTauL + P.sTA + P.sP1 + P.sB + P.sW + P.sT + P.sRt +
-                              P.sTauJ + P.sZ + P.sVec + P.sM + P.sVb + P.sDiag + 2 * P.sVn;
+                              P.sTauJ + P.sZ + P.sVec + P.sM + P.sVb + P.sDiag + 2 * P.sVn + PB * PB;
     const long long per_i64 = P.sJA + P.sJL + P.sJJ;
     const long long per_i32 = 6 * P.sQI;   // chosen + 2 x pos + 2 x colat + inblk
     const size_t bytes = (size_t)batch * (per_dbl * 8 + per_i64 * 8 + per_i32 * 4 + P.sCand * sizeof(QdCand)) +
@@ -123,6 +124,7 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     h->zsave = (double*)carve(P.sZ); h->vec = (double*)carve(P.sVec);
     h->qdM = (double*)carve(P.sM); h->qdVb = (double*)carve(P.sVb); h->qdDiag = (double*)carve(P.sDiag);
     h->qdVn1 = (double*)carve(P.sVn); h->qdVn2 = (double*)carve(P.sVn);
+    h->sbT = (double*)carve(PB * PB);
     h->jpvtA = (long long*)carve(P.sJA); h->jpvtL = (long long*)carve(P.sJL); h->jpvtJ = (long long*)carve(P.sJJ);
     h->qdChosen = (int*)p; p += (size_t)batch * P.sQI * 4;
     h->qdPos = (int*)p; p += (size_t)batch * 2 * P.sQI * 4;
@@ -198,8 +200,13 @@ static CaqrArgs caqr_args(enlsip_gn_handle h, int k, const LevelPlan& L) {
 
 static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
     dim3 grid(groups, (unsigned)h->plan.batch);
-    if (h->plan.RPL == 8) hipLaunchKernelGGL(k_caqr_factor<8>, grid, dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(k_caqr_factor<4>, grid, dim3(256), 0, h->stream, a);
+    if (h->factor_waves == 8) {
+        if (h->plan.RPL == 8) hipLaunchKernelGGL((k_caqr_factor<8, 8>), grid, dim3(512), 0, h->stream, a);
+        else hipLaunchKernelGGL((k_caqr_factor<4, 8>), grid, dim3(512), 0, h->stream, a);
+    } else {
+        if (h->plan.RPL == 8) hipLaunchKernelGGL((k_caqr_factor<8, 4>), grid, dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL((k_caqr_factor<4, 4>), grid, dim3(256), 0, h->stream, a);
+    }
 }
 static void launch_update_refl(enlsip_gn_handle h, const CaqrArgs& a, int groups, int ncols) {
     dim3 grid(groups, (ncols + 31) / 32, (unsigned)h->plan.batch);
@@ -292,6 +299,7 @@ static int run_qrcp_dist(enlsip_gn_handle h, int n2_launch) {
 }
 
 // blocked pivoted QR of R0 with verified pivots (gn_kernels_qrcp_block.hpp)
+static inline bool big_kp(int kp) { return kp > 512; }
 static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     const Plan& P = h->plan;
     const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
@@ -305,6 +313,9 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     q.cand = (QdCand*)h->qdCand; q.sCand = P.sCand; q.Gmax = P.qdGmax;
     q.jpvt = h->jpvtJ; q.sJ = P.sJJ; q.state = h->state;
     a.info = (SbInfo*)h->sbInfo; a.inblk = h->sbInblk; a.sIn = P.sQI; a.blkid = 0;
+    a.Tsb = h->sbT; a.sTsb = PB * PB;
+    const bool blk_update = !big_kp(kp_launch) && !getenv("ENLSIP_GN_SB_STEPWISE");   // MFMA block update (kp <= 512)
+    if (!blk_update) a.Tsb = nullptr;
     a.dbg = nullptr;
     if (getenv("ENLSIP_GN_SB_DEBUG")) {   // diagnostic: per-block phase stamps of problem 0 into the scratch buffer
         if (grow(h, h->scratch, 8 * 8 * 1024) == 0) {
@@ -333,7 +344,8 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
                 hipLaunchKernelGGL(k_sb_update<16>, ugrid, dim3(256), 0, s, a);
             } else {
                 hipLaunchKernelGGL(k_sb_factor<8>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
-                hipLaunchKernelGGL(k_sb_update<8>, ugrid, dim3(256), 0, s, a);
+                if (blk_update) hipLaunchKernelGGL(k_sb_update_blk, ugrid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL(k_sb_update<8>, ugrid, dim3(256), 0, s, a);
             }
         }
         GN_HIP(hipGetLastError());
@@ -579,6 +591,8 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         h->qrcp_mode = 2;                                    // default: blocked with verified pivots
         if (qm && qm[0] == 'p') h->qrcp_mode = 0;            // persist
         if (qm && qm[0] == 's') h->qrcp_mode = 1;            // step: one launch per pivot step
+        const char* fw = getenv("ENLSIP_GN_FACTOR_WAVES");   // 4 or 8 waves per panel-factor workgroup (A/B switch)
+        if (fw && fw[0] == '4') h->factor_waves = 4;
     }
     if (opts && opts->panel_width != 0 && opts->panel_width != PB) {
         delete h;

@@ -64,12 +64,14 @@ struct enlsip_gn_context {
     int *qdChosen = nullptr, *qdPos = nullptr, *qdColat = nullptr;
     void* qdCand = nullptr;
     unsigned* abort_word = nullptr;
+    double* sbT = nullptr;       // per problem: T factor of the current QRCP block (32 x 32)
     void* sbInfo = nullptr;      // SbInfo per problem (device)
     int* sbInblk = nullptr;      // per column block id (device)
     void* h_sbinfo = nullptr;    // pinned mirror of sbInfo
     int cu_count = 256;
     enlsip_gn_context* sub = nullptr;   // handle for the stacked problem of the TSQR combine stage
     long long tsqr_n2 = -1;             // n2 of the last tsqr_local on this handle
+    int factor_waves = 8;   // waves per workgroup of k_caqr_factor (ENLSIP_GN_FACTOR_WAVES=4 selects the 4-wave form)
     int qrcp_mode = 2;   // 0 persistent (co-resident workgroups), 1 one launch per pivot step, 2 blocked with verified pivots
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
     gn::ProbState* state = nullptr;

@@ -101,6 +101,32 @@ __device__ __forceinline__ void wave_allsum8(const double (&d)[8], double (&out)
     for (int c = 0; c < 8; ++c) out[c] = readlane_f64(k1, 8 * (c >> 2) + 4 * ((c >> 1) & 1) + 2 * (c & 1));
 }
 
+// Four-column version of wave_allsum8 (lane l ends with column 2*bit2 + bit1).
+__device__ __forceinline__ void wave_allsum4(const double (&d)[4], double (&out)[4]) {
+    const int ln = threadIdx.x & 63;
+    const bool b2 = (ln & 4) != 0, b1 = (ln & 2) != 0;
+    double k2[2], k1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const double mine = b2 ? d[c + 2] : d[c];
+        const double give = b2 ? d[c] : d[c + 2];
+        k2[c] = mine + dpp_f64<0x141>(give);
+    }
+    {
+        const double mine = b1 ? k2[1] : k2[0];
+        const double give = b1 ? k2[0] : k2[1];
+        k1 = mine + dpp_f64<0x1B>(give);     // quad_perm [3,2,1,0]
+    }
+    k1 += dpp_f64<0xB1>(k1);                 // quad_perm [1,0,3,2]
+    k1 += dpp_f64<0x128>(k1);                // row_ror:8 (the other half of the row holds the same column)
+    k1 = xor16_sum(k1);
+    k1 = xor32_sum(k1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = readlane_f64(k1, 4 * (c >> 1) + 2 * (c & 1));
+}
+__device__ __forceinline__ void wave_allsumN(const double (&d)[8], double (&out)[8]) { wave_allsum8(d, out); }
+__device__ __forceinline__ void wave_allsumN(const double (&d)[4], double (&out)[4]) { wave_allsum4(d, out); }
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int x) {
     return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);

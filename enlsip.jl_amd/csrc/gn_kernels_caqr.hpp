@@ -44,8 +44,16 @@ struct CaqrArgs {
 // ---------------------------------------------------------------------------------------------
 // panel factorisation of one group (tile or tree node)
 // ---------------------------------------------------------------------------------------------
-template <int RPL>
-__global__ __launch_bounds__(256, 2) void k_caqr_factor(CaqrArgs a) {
+// NW waves per workgroup; wave w owns the NC = 32 / NW panel columns w + NW cc.  NW = 8 halves the per-step
+// dependency chain of a wave (4 dot products + one 4-way transposed reduction + 4 column updates) and doubles
+// the waves per SIMD that hide it.
+template <int RPL, int NW>
+#ifndef ENLSIP_FACTOR_OCC8
+#define ENLSIP_FACTOR_OCC8 4
+#endif
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_caqr_factor(CaqrArgs a) {   // 2nd bound = waves per SIMD
+    constexpr int NC = PB / NW;
+    constexpr int NT = 64 * NW;
     __shared__ double vsh[2][64 * RPL];
     __shared__ double taush[PB];
     __shared__ double gsh[PB][PB + 1];
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void k_caqr_factor(CaqrArgs a) {
     double* W = a.W + prob * a.sW;
     const bool tri = a.level > 0;
 
-    for (int e = threadIdx.x; e < PB * (PB + 1); e += 256) (&gsh[0][0])[e] = 0.0;
+    for (int e = threadIdx.x; e < PB * (PB + 1); e += NT) (&gsh[0][0])[e] = 0.0;
     if (threadIdx.x < PB) taush[threadIdx.x] = 0.0;
 
     // slot geometry of this lane
@@ -75,11 +83,11 @@ __global__ __launch_bounds__(256, 2) void k_caqr_factor(CaqrArgs a) {
         bval[i] = bidx < a.nblocks;
         rowoff[i] = r0 + bidx * a.S + rb;
     }
-    // load the tile: a[cc][i] = element (slot ln + 64 i, column w + 4 cc)
-    double x[8][RPL];
+    // load the tile: a[cc][i] = element (slot ln + 64 i, column w + NW cc)
+    double x[NC][RPL];
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-        const int c = w + 4 * cc;
+    for (int cc = 0; cc < NC; ++cc) {
+        const int c = w + NW * cc;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             const bool ok = (c < bw) && bval[i] && (!tri || rb <= c);
@@ -89,9 +97,9 @@ __global__ __launch_bounds__(256, 2) void k_caqr_factor(CaqrArgs a) {
     __syncthreads();
 
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        for (int jw = 0; jw < 4; ++jw) {
-            const int j = 4 * jj + jw;  // wave-uniform
+    for (int jj = 0; jj < NC; ++jj) {
+        for (int jw = 0; jw < NW; ++jw) {
+            const int j = NW * jj + jw;  // wave-uniform
             if (j < bw) {
                 const int buf = j & 1;
                 if (w == jw) {
@@ -118,18 +126,18 @@ __global__ __launch_bounds__(256, 2) void k_caqr_factor(CaqrArgs a) {
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) v[i] = vsh[buf][ln + 64 * i];
                 const double tj = taush[j];
-                double dot[8];
+                double dot[NC];
 #pragma unroll
-                for (int cc = 0; cc < 8; ++cc) {
+                for (int cc = 0; cc < NC; ++cc) {
                     dot[cc] = 0.0;
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) dot[cc] += x[cc][i] * v[i];
                 }
-                double ds[8];
-                wave_allsum8(dot, ds);     // eight reductions for the price of ~three
+                double ds[NC];
+                wave_allsumN(dot, ds);     // NC reductions sharing one transposed butterfly
 #pragma unroll
-                for (int cc = 0; cc < 8; ++cc) {
-                    const int c = w + 4 * cc;
+                for (int cc = 0; cc < NC; ++cc) {
+                    const int c = w + NW * cc;
                     if (c > j) {
                         const double wd = tj * ds[cc];
 #pragma unroll
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void k_caqr_factor(CaqrArgs a) {
     __syncthreads();
     // store the tile back (V below / R on and above the diagonal; tree levels: upper triangles)
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-        const int c = w + 4 * cc;
+    for (int cc = 0; cc < NC; ++cc) {
+        const int c = w + NW * cc;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             const bool ok = (c < bw) && bval[i] && (!tri || rb <= c);

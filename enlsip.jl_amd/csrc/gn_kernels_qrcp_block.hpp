@@ -20,6 +20,7 @@
 // the LAPACK-style compact factors at the end (shared with gn_kernels_qrcp_dist.hpp).
 #pragma once
 #include "gn_kernels_qrcp_dist.hpp"
+#include "gn_kernels_update_v4.hpp"
 
 namespace gn {
 
@@ -39,6 +40,7 @@ struct SbArgs {
     SbInfo* info;     // per problem
     int* inblk;       long long sIn;    // per physical column: id of the last block it was a candidate in
     int blkid;
+    double* Tsb;      long long sTsb;   // per problem: dlarft T (32 x 32, column-major) of the last block's reflectors
     long long* dbg;   // optional (diagnostic builds): 8 realtime stamps per block of problem prob0
 };
 
@@ -53,6 +55,9 @@ struct SbLds {
     int ccol[SB_KMAX], cpos[2][SB_KMAX];      // reads [s & 1] and writes [(s + 1) & 1] -> one barrier per step
     int rankl[SB_NMAX];
     double taul[SB_KMAX], betal[SB_KMAX];     // per candidate slot: tau / beta of the step that retired it
+    double gram[32 * 33];                     // v_a' v_b of the block's reflectors (a < b)
+    double tmat[32 * 33];                     // T factor, row a in lane a
+    int tslot[32];                            // candidate slot of the block's t-th reflector
     double bval;
     int bpos;
     int K;
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(1024) void k_sb_factor(SbArgs a) {
     for (;; ++s) {
         const int j = j0 + s;
         if (j >= kp) break;
+        if (a.Tsb != nullptr && s >= 32) break;     // the blocked update applies at most 32 reflectors at once
         const int rd = s & 1, wr = rd ^ 1;
         if (pend >= 0) {   // reflector of the previous step -> LDS column of the candidate it retired
             double* colp = L.slab + (size_t)pend * ldk;
@@ -291,6 +297,50 @@ __global__ __launch_bounds__(1024) void k_sb_factor(SbArgs a) {
         }
     }
     __syncthreads();
+    // ---- 4b. T factor (dlarft, forward / columnwise) of the block's s <= 32 reflectors, for the blocked
+    // MFMA update of the outside columns (k_sb_update_blk).  Reflector t lives in the LDS column of the
+    // candidate it retired: rows t + 1 .. rows - 1 (block-local), implicit one at row t.
+    if (a.Tsb != nullptr && s <= 32) {
+        if (tid < K) {
+            const int pk = L.cpos[fin][tid];
+            if (pk < 0) {
+                const int t = (-1 - pk) - j0;
+                if (t >= 0 && t < s) L.tslot[t] = tid;
+            }
+        }
+        __syncthreads();
+        for (int b = w; b < s; b += 16) {
+            const double* cb = L.slab + (size_t)L.tslot[b] * ldk;
+            for (int aa = 0; aa < b; ++aa) {
+                const double* ca = L.slab + (size_t)L.tslot[aa] * ldk;
+                double dot = 0.0;
+                for (int r = b + 1 + ln; r < rows; r += WAVE) dot += ca[r] * cb[r];
+                dot = wave_allsum(dot);
+                if (ln == 0) L.gram[aa * 33 + b] = dot + ca[b];
+            }
+        }
+        __syncthreads();
+        if (w == 0) {
+            double* T = a.Tsb + prob * a.sTsb;
+            if (ln < 32) {
+                double* trow = L.tmat + ln * 33;
+                for (int b = 0; b < 32; ++b) {
+                    double tv = 0.0;
+                    if (b < s && ln <= b) {
+                        const double tb = L.taul[L.tslot[b]];
+                        if (ln == b) tv = tb;
+                        else {
+                            double acc = 0.0;
+                            for (int l = ln; l < b; ++l) acc += trow[l] * L.gram[l * 33 + b];
+                            tv = -tb * acc;
+                        }
+                    }
+                    trow[b] = tv;
+                    T[ln + b * 32] = tv;
+                }
+            }
+        }
+    }
     // ---- 5. write back --------------------------------------------------------------------------------
     for (int k = w; k < K; k += 16) {
         const int c = L.ccol[k];
@@ -462,6 +512,125 @@ __global__ __launch_bounds__(256) void k_sb_update(SbArgs a) {
         vn1[myc] = my_o1;
         vn2[myc] = my_o2;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked form of the update above (kp <= 512): the block's s reflectors are applied to 32 outside
+// columns at once as C <- C - V (T' (V' C)) on the matrix pipe — the workgroup body of the CAQR trailing
+// update (gn_kernels_update_v4.hpp) with element-granular row masks (the row range starts at the
+// arbitrary pivot step jb) — followed by the dlaqp2 norm downdates of those columns.
+// The downdate of step t needs the entry of row jb + t after reflectors 0..t; later reflectors do not
+// touch that row, so it is the FINAL entry.  A recomputation (cancellation test of dlaqp2) needs the norm
+// of the rows below jb + t at that point; the later reflectors act on exactly those rows and are
+// orthogonal, so it equals sqrt(sum of the final squares of rows > jb + t) — taken from the R rows of
+// the block and a per-column sum of squares of the rows below them.
+// ---------------------------------------------------------------------------------------------
+struct SbPost {           // per-unit hook of v4_body: sums of squares below the R rows + export of unit 0
+    double* acc8;         // [8] per lane: column 16 ct + lq + 4 r  <->  index 4 ct + r
+    double* img;          // wave 0: [col][row] image (ld V4_LD) of the block's first 32 rows
+    int w, lr, lq, s;
+    template <class F>
+    __device__ __forceinline__ void operator()(int g, const F& fr) const {
+        const int s0 = 32 * (w + 4 * g) + 2 * lr;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double x0 = fr[0][ct][r], x1 = fr[1][ct][r];
+                acc8[4 * ct + r] += ((s0 >= s) ? x0 * x0 : 0.0) + ((s0 + 1 >= s) ? x1 * x1 : 0.0);
+                if (g == 0 && w == 0) *(v4_d2*)&img[(16 * ct + lq + 4 * r) * V4_LD + 2 * lr] = (v4_d2){x0, x1};
+            }
+    }
+};
+
+__global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
+    __shared__ __attribute__((aligned(16))) double stage[4][V4_STAGE];
+    __shared__ __attribute__((aligned(16))) double W2l[PB * PB];
+    __shared__ double ssq[4][32];
+
+    const int prob = blockIdx.y + a.q.prob0;
+    const ProbState st = a.q.state[prob];
+    const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
+    const SbInfo info = a.info[prob];
+    if (info.blk != a.blkid || info.s == 0) return;     // this problem did no step in this block
+    const int jb = info.pad, s = info.s;
+    const int cb0 = blockIdx.x * 32;
+    if (cb0 >= ctot) return;
+    const int ln = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const int lr = ln & 15, lq = ln >> 4;
+    const int* chosen = a.q.chosen + prob * a.q.sI;
+    const int* inblk = a.inblk + prob * a.sIn;
+    // activity of the block's 32 columns (identical in every wave)
+    bool act = false;
+    if (ln < 32) {
+        const int c = cb0 + ln;
+        act = (c == n2) || (c < n2 && chosen[c] < 0 && inblk[c] != a.blkid);
+    }
+    const unsigned actbits = (unsigned)(__ballot(act) & 0xffffffffull);
+    if (actbits == 0u) return;
+    unsigned vmask = 0u, smask = 0u;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int cl = 16 * (b >> 2) + 4 * (b & 3) + lq;
+        vmask |= (cb0 + cl < ctot) ? (1u << b) : 0u;
+        smask |= ((actbits >> cl) & 1u) ? (1u << b) : 0u;
+    }
+    V4Ctx c;
+    c.Wm = a.q.Vb + prob * a.q.sVb;
+    c.C = a.q.M + prob * a.q.sM;
+    c.T = a.Tsb + prob * a.sTsb;
+    c.tile_row0 = jb; c.r0 = jb; c.gblk0 = 0; c.S = 0;
+    c.ldw = a.q.ldr; c.col0 = jb; c.bw = s; c.cb0 = cb0;
+    c.rows_valid = kp - jb;
+    const int nvu = (c.rows_valid + 31) / 32;
+    const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;
+
+    double acc8[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc8[b] = 0.0;
+    SbPost post{acc8, stage[0], w, lr, lq, s};
+    if (ctot - cb0 <= 16) v4_dispatch<8, false, false, 1, true, SbPost>(c, w, ngw, stage, W2l, vmask, smask, post);
+    else v4_dispatch<8, false, false, 2, true, SbPost>(c, w, ngw, stage, W2l, vmask, smask, post);
+
+    // per-column sums of squares: reduce over the 16 row-pair lanes, one writer per (wave, column)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        double x = acc8[b];
+        x += dpp_f64<0xB1>(x);
+        x += dpp_f64<0x4E>(x);
+        x += dpp_f64<0x141>(x);
+        x += dpp_f64<0x140>(x);
+        if (lr == 0) ssq[w][16 * (b >> 2) + 4 * (b & 3) + lq] = x;
+    }
+    __syncthreads();
+    if (w != 0 || ln >= 32) return;
+    const int cc = cb0 + ln;
+    if (!((actbits >> ln) & 1u) || cc >= n2) return;
+    double* vn1 = a.q.vn1 + prob * a.q.sVn;
+    double* vn2 = a.q.vn2 + prob * a.q.sVn;
+    const double tol3z = 1.4901161193847656e-08;
+    const double srest = (ssq[0][ln] + ssq[1][ln]) + (ssq[2][ln] + ssq[3][ln]);
+    const double* col = stage[0] + ln * V4_LD;            // final entries of rows jb .. jb + 31 of this column
+    double o1 = vn1[cc], o2 = vn2[cc];
+    for (int t = 0; t < s; ++t) {
+        if (o1 == 0.0) continue;
+        const double ajc = col[t];
+        double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
+        temp = temp > 0.0 ? temp : 0.0;
+        const double qq = o1 / o2;
+        const double temp2 = temp * qq * qq;
+        if (temp2 <= tol3z) {
+            double sq = srest;
+            for (int t2 = s - 1; t2 > t; --t2) sq += col[t2] * col[t2];
+            o1 = (jb + t + 1 < kp) ? sqrt(sq) : 0.0;
+            o2 = o1;
+        } else {
+            o1 = o1 * sqrt(temp);
+        }
+    }
+    vn1[cc] = o1;
+    vn2[cc] = o2;
 }
 
 }  // namespace gn

@@ -59,7 +59,12 @@ struct V4Ctx {
     double* C;            // first trailing column
     const double* T;
     long long tile_row0, r0, gblk0, S;
-    int ldw, col0, bw, ncols, cb0;
+    int ldw, col0, bw, cb0;
+    int rows_valid;       // RMASK only: slots >= rows_valid do not exist (element granularity)
+};
+
+struct V4NoPost {         // default post-update hook: nothing
+    template <class F> __device__ __forceinline__ void operator()(int, const F&) const {}
 };
 
 // TRI   = false: level 0 (contiguous rows, V = unit lower trapezoid);  true: tree node (unit G is block
@@ -69,8 +74,15 @@ struct V4Ctx {
 //         is straight-line code.
 // NCT   = 16-column tiles in use: 1 for a last block of <= 16 columns (the carried right-hand side makes
 //         the column count 32 k + 1, so every panel ends with such a block).
-template <int RPL, bool TRI, bool CFULL, int NGW, int NCT>
-__device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*stage)[V4_STAGE], double* W2l) {
+// RMASK = true : the last unit may be partial at element granularity (c.rows_valid); used by the blocked
+//         pivoted QR, whose row range starts at an arbitrary pivot step.
+// vmask / smask (per lane, bit 4 ct + r <-> column 16 ct + lq + 4 r of the block; ignored when CFULL):
+//         column holds valid data / column is written back.
+// post(g, fr): called with the updated fragments of unit g (fr[p][ct][r] = row pair element p of column
+//         16 ct + lq + 4 r) before they are stored.
+template <int RPL, bool TRI, bool CFULL, int NGW, int NCT, bool RMASK = false, class Post = V4NoPost>
+__device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*stage)[V4_STAGE], double* W2l,
+                                        const unsigned vmask = ~0u, const unsigned smask = ~0u, const Post& post = Post()) {
     const int ln = lane_id();
     const int lr = ln & 15, lq = ln >> 4;
     const int it2 = w >> 1, ct2 = w & 1;             // W2 tile produced by this wave in the reduction step
@@ -110,9 +122,10 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool ok = c.cb0 + 16 * ct + 4 * r + lq < c.ncols;
-                cp[g][ct][r][0] = ok ? cp[g][ct][r][0] : 0.0;
-                cp[g][ct][r][1] = ok ? cp[g][ct][r][1] : 0.0;
+                const bool ok = (vmask >> (4 * ct + r)) & 1u;
+                const int s0 = slot0(g) + 2 * lr;
+                cp[g][ct][r][0] = (ok && (!RMASK || s0 < c.rows_valid)) ? cp[g][ct][r][0] : 0.0;
+                cp[g][ct][r][1] = (ok && (!RMASK || s0 + 1 < c.rows_valid)) ? cp[g][ct][r][1] : 0.0;
             }
     };
     // V operands are fetched in halves of 4 contraction steps: vh[k4] = V[row pair][vcol 16 h + 4 k4 + lq]
@@ -138,7 +151,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                     const double tri = ((s & 31) <= j) ? x : 0.0;
                     x = (g == 0 && s < PB) ? ((s == j) ? 1.0 : 0.0) : tri;
                 }
-                if (!CFULL) x = (j < c.bw) ? x : 0.0;
+                if (!CFULL) x = (j < c.bw && (!RMASK || s < c.rows_valid)) ? x : 0.0;
                 vh[k4][p] = x;
             }
         }
@@ -242,6 +255,10 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
+            for (int ct = NCT; ct < 2; ++ct) fr[p][ct] = (v4_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
             for (int ct = 0; ct < NCT; ++ct) fr[p][ct] = (v4_d4){cp[g][ct][0][p], cp[g][ct][1][p], cp[g][ct][2][p], cp[g][ct][3][p]};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -264,29 +281,37 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        post(g, fr);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (V4_ABLATE == 3 || V4_ABLATE == 5) {
                     if (fr[0][ct][r] == 1.2345e301) c.C[0] = fr[1][ct][r];
-                } else if (CFULL || c.cb0 + 16 * ct + 4 * r + lq < c.ncols) {
-                    *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
+                } else if (CFULL || ((smask >> (4 * ct + r)) & 1u)) {
+                    if (!RMASK) {
+                        *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
+                    } else {
+                        const int s0 = slot0(g) + 2 * lr;
+                        if (s0 + 1 < c.rows_valid) *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
+                        else if (s0 < c.rows_valid) *cptr(g, ct, r) = fr[0][ct][r];
+                    }
                 }
             }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int RPL, bool TRI, bool CFULL, int NCT>
-__device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, double (*stage)[V4_STAGE], double* W2l) {
+template <int RPL, bool TRI, bool CFULL, int NCT, bool RMASK = false, class Post = V4NoPost>
+__device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, double (*stage)[V4_STAGE], double* W2l,
+                                            const unsigned vmask = ~0u, const unsigned smask = ~0u, const Post& post = Post()) {
     constexpr int NG = RPL / 2;
     // every variant executes exactly two workgroup barriers, so waves of one workgroup may take different ones
-    if (ngw >= NG) v4_body<RPL, TRI, CFULL, NG, NCT>(c, w, stage, W2l);
-    else if (NG > 3 && ngw == 3) v4_body<RPL, TRI, CFULL, (NG > 3 ? 3 : 0), NCT>(c, w, stage, W2l);
-    else if (NG > 2 && ngw == 2) v4_body<RPL, TRI, CFULL, (NG > 2 ? 2 : 0), NCT>(c, w, stage, W2l);
-    else if (NG > 1 && ngw == 1) v4_body<RPL, TRI, CFULL, (NG > 1 ? 1 : 0), NCT>(c, w, stage, W2l);
-    else v4_body<RPL, TRI, CFULL, 0, NCT>(c, w, stage, W2l);
+    if (ngw >= NG) v4_body<RPL, TRI, CFULL, NG, NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
+    else if (NG > 3 && ngw == 3) v4_body<RPL, TRI, CFULL, (NG > 3 ? 3 : 0), NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
+    else if (NG > 2 && ngw == 2) v4_body<RPL, TRI, CFULL, (NG > 2 ? 2 : 0), NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
+    else if (NG > 1 && ngw == 1) v4_body<RPL, TRI, CFULL, (NG > 1 ? 1 : 0), NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
+    else v4_body<RPL, TRI, CFULL, 0, NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
 }
 
 template <int RPL, bool TRI>
@@ -303,9 +328,10 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4(CaqrArgs a) {
     c.col0 = st.rankA + r0;
     const int g = blockIdx.x;
     const int first = r0 + c.bw;
-    c.ncols = st.n2 + 1 - first;
+    const int ncols = st.n2 + 1 - first;
     c.cb0 = blockIdx.y * 32;
-    if (c.cb0 >= c.ncols) return;
+    if (c.cb0 >= ncols) return;
+    c.rows_valid = 0;
     c.Wm = a.W + prob * a.sW;
     c.C = a.W + prob * a.sW + (size_t)(st.rankA + first) * a.ldw;
     c.T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
@@ -318,10 +344,16 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4(CaqrArgs a) {
     const int nvu = (int)(blocks_here < a.F ? blocks_here : a.F);        // valid 32-row units of this group
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
     const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;                     // units w, w + 4, ... < nvu
-    const bool cfull = (c.ncols - c.cb0 >= 32) && (c.bw == PB);
+    const bool cfull = (ncols - c.cb0 >= 32) && (c.bw == PB);
+    unsigned cmask = 0u;       // valid (= stored) columns of this lane
+    {
+        const int lq = lane_id() >> 4;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) cmask |= (c.cb0 + 16 * (b >> 2) + 4 * (b & 3) + lq < ncols) ? (1u << b) : 0u;
+    }
     if (cfull) v4_dispatch<RPL, TRI, true, 2>(c, w, ngw, stage, W2l);
-    else if (c.ncols - c.cb0 <= 16) v4_dispatch<RPL, TRI, false, 1>(c, w, ngw, stage, W2l);
-    else v4_dispatch<RPL, TRI, false, 2>(c, w, ngw, stage, W2l);
+    else if (ncols - c.cb0 <= 16) v4_dispatch<RPL, TRI, false, 1>(c, w, ngw, stage, W2l, cmask, cmask);
+    else v4_dispatch<RPL, TRI, false, 2>(c, w, ngw, stage, W2l, cmask, cmask);
 }
 
 inline void launch_update_v4(int RPL, const CaqrArgs& a, int groups, int ncols, int batch, hipStream_t s) {
