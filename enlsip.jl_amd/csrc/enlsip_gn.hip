@@ -334,7 +334,9 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     if (big) big_lds(k_sb_factor<16>, lds); else big_lds(k_sb_factor<8>, lds);
     dim3 ugrid((n2_launch + 1 + SB_UCW - 1) / SB_UCW, (unsigned)P.batch);
     int it = 0;
-    int chunk = std::min(kp_launch, 22);   // ~20 blocks factor a C2 problem; re-check in small chunks after that
+    // blocks of <= 32 steps; the first chunk is sized from the previous solve on this handle (one host check per
+    // solve in steady state), later chunks are small
+    int chunk = std::min(kp_launch, h->sb_hint > 0 ? h->sb_hint : kp_launch / 16 + 4);
     SbInfo* hinfo = (SbInfo*)h->h_sbinfo;
     while (it < kp_launch) {
         for (int i = 0; i < chunk && it < kp_launch; ++i, ++it) {
@@ -354,7 +356,12 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
         GN_HIP(hipStreamSynchronize(s));
         bool done = true;
         for (long long k = 0; k < P.batch; ++k) done = done && (hinfo[k].j0 >= h->h_state[k].kp);
-        if (done) break;
+        if (done) {
+            int used = 0;
+            for (long long k = 0; k < P.batch; ++k) used = std::max(used, hinfo[k].blk + 1);
+            h->sb_hint = used + 1;
+            break;
+        }
         chunk = 4;
     }
     hipLaunchKernelGGL(k_qd_assemble, grid, dim3(256), 0, s, q);

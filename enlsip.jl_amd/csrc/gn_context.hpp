@@ -64,6 +64,7 @@ struct enlsip_gn_context {
     int *qdChosen = nullptr, *qdPos = nullptr, *qdColat = nullptr;
     void* qdCand = nullptr;
     unsigned* abort_word = nullptr;
+    int sb_hint = 0;             // blocks the previous blocked QRCP needed (+1): size of the first launch chunk
     double* sbT = nullptr;       // per problem: T factor of the current QRCP block (32 x 32)
     void* sbInfo = nullptr;      // SbInfo per problem (device)
     int* sbInblk = nullptr;      // per column block id (device)

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(1024) void k_sb_factor(SbArgs a) {
     for (;; ++s) {
         const int j = j0 + s;
         if (j >= kp) break;
-        if (a.Tsb != nullptr && s >= 32) break;     // the blocked update applies at most 32 reflectors at once
+        if (a.Tsb != nullptr && s >= 32 - (j0 & 1)) break;   // the blocked update applies <= 32 reflectors whose R rows fit its first (16-byte aligned) 32-row unit
         const int rd = s & 1, wr = rd ^ 1;
         if (pend >= 0) {   // reflector of the previous step -> LDS column of the candidate it retired
             double* colp = L.slab + (size_t)pend * ldk;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_sb_update(SbArgs a) {
 struct SbPost {           // per-unit hook of v4_body: sums of squares below the R rows + export of unit 0
     double* acc8;         // [8] per lane: column 16 ct + lq + 4 r  <->  index 4 ct + r
     double* img;          // wave 0: [col][row] image (ld V4_LD) of the block's first 32 rows
-    int w, lr, lq, s;
+    int w, lr, lq, s;     // s = first slot below the block's R rows (steps + alignment shift)
     template <class F>
     __device__ __forceinline__ void operator()(int g, const F& fr) const {
         const int s0 = 32 * (w + 4 * g) + 2 * lr;
@@ -580,16 +580,18 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
     c.Wm = a.q.Vb + prob * a.q.sVb;
     c.C = a.q.M + prob * a.q.sM;
     c.T = a.Tsb + prob * a.sTsb;
-    c.tile_row0 = jb; c.r0 = jb; c.gblk0 = 0; c.S = 0;
+    const int d = jb & 1;                 // start one row early when jb is odd: every row pair is 16-byte aligned
+    c.tile_row0 = jb - d; c.r0 = jb - d; c.gblk0 = 0; c.S = 0;
     c.ldw = a.q.ldr; c.col0 = jb; c.bw = s; c.cb0 = cb0;
-    c.rows_valid = kp - jb;
+    c.rows_valid = kp - (jb - d);
+    c.dshift = d;
     const int nvu = (c.rows_valid + 31) / 32;
     const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;
 
     double acc8[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc8[b] = 0.0;
-    SbPost post{acc8, stage[0], w, lr, lq, s};
+    SbPost post{acc8, stage[0], w, lr, lq, s + d};
     if (ctot - cb0 <= 16) v4_dispatch<8, false, false, 1, true, SbPost>(c, w, ngw, stage, W2l, vmask, smask, post);
     else v4_dispatch<8, false, false, 2, true, SbPost>(c, w, ngw, stage, W2l, vmask, smask, post);
 
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
     double* vn2 = a.q.vn2 + prob * a.q.sVn;
     const double tol3z = 1.4901161193847656e-08;
     const double srest = (ssq[0][ln] + ssq[1][ln]) + (ssq[2][ln] + ssq[3][ln]);
-    const double* col = stage[0] + ln * V4_LD;            // final entries of rows jb .. jb + 31 of this column
+    const double* col = stage[0] + ln * V4_LD + d;        // final entries of rows jb .. jb + 31 of this column
     double o1 = vn1[cc], o2 = vn2[cc];
     for (int t = 0; t < s; ++t) {
         if (o1 == 0.0) continue;

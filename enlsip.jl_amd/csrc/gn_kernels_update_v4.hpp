@@ -61,6 +61,8 @@ struct V4Ctx {
     long long tile_row0, r0, gblk0, S;
     int ldw, col0, bw, cb0;
     int rows_valid;       // RMASK only: slots >= rows_valid do not exist (element granularity)
+    int dshift;           // level 0: the diagonal of reflector j sits in slot j + dshift (0 for the CAQR; the blocked
+                          // pivoted QR starts its units one row early when its first row is odd, for 16-byte alignment)
 };
 
 struct V4NoPost {         // default post-update hook: nothing
@@ -146,7 +148,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                 const int s = s0 + p;
                 double x = vh[k4][p];
                 if (!TRI) {
-                    if (g == 0) x = (s > j) ? x : ((s == j) ? 1.0 : 0.0);     // only slots < 32 (unit 0) carry the trapezoid
+                    if (g == 0) x = (s > j + c.dshift) ? x : ((s == j + c.dshift) ? 1.0 : 0.0);   // only units 0..3 can meet the diagonal
                 } else {
                     const double tri = ((s & 31) <= j) ? x : 0.0;
                     x = (g == 0 && s < PB) ? ((s == j) ? 1.0 : 0.0) : tri;
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4(CaqrArgs a) {
     c.cb0 = blockIdx.y * 32;
     if (c.cb0 >= ncols) return;
     c.rows_valid = 0;
+    c.dshift = 0;
     c.Wm = a.W + prob * a.sW;
     c.C = a.W + prob * a.sW + (size_t)(st.rankA + first) * a.ldw;
     c.T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
