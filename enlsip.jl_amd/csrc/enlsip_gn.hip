@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "gn_context.hpp"
 #include "gn_kernels_caqr.hpp"
@@ -423,6 +424,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
                      double eps_rank, long long dimA_ov, long long dimJ2_ov,
                      double* dp, double* db, double* dd, enlsip_gn_info* dinfo,
                      long long* djA, long long* djL, long long* djJ) {
+    h->split = 0;   // routing of accessors to the pipeline child is (re)established by the batched entry point
     int rc = check_limits(h, batch, m, n, t);
     if (rc) return rc;
     if (ldj < m) { h->err = "ldj < m"; return -7; }
@@ -600,6 +602,8 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (qm && qm[0] == 's') h->qrcp_mode = 1;            // step: one launch per pivot step
         const char* fw = getenv("ENLSIP_GN_FACTOR_WAVES");   // 4 or 8 waves per panel-factor workgroup (A/B switch)
         if (fw && fw[0] == '4') h->factor_waves = 4;
+        const char* pl = getenv("ENLSIP_GN_PIPELINE");       // 0: never split a batch over two streams
+        if (pl && pl[0] == '0') h->pipeline = false;
     }
     if (opts && opts->panel_width != 0 && opts->panel_width != PB) {
         delete h;
@@ -639,16 +643,23 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->upd_ev) (void)hipEventDestroy(e);
     if (h->sub) (void)enlsip_gn_destroy(h->sub);
+    if (h->child) (void)enlsip_gn_destroy(h->child);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }
 
-const char* enlsip_gn_last_error(enlsip_gn_handle h) { return h ? h->err.c_str() : "null handle"; }
+const char* enlsip_gn_last_error(enlsip_gn_handle h) {
+    if (!h) return "null handle";
+    if (h->err.empty() && h->child && !h->child->err.empty()) return h->child->err.c_str();
+    return h->err.c_str();
+}
 
 int enlsip_gn_synchronize(enlsip_gn_handle h) {
     if (!h) return -1;
     GN_HIP(hipStreamSynchronize(h->stream));
+    if (h->child) GN_HIP(hipStreamSynchronize(h->child->stream));
     return 0;
 }
 
@@ -682,6 +693,43 @@ int enlsip_gn_solve_batched_dev(enlsip_gn_handle h, int64_t batch, int64_t m, in
     if (!dJ) return -6;
     if (!drx) return -9;
     if (t > 0 && (!dAt || !dcx)) return -10;
+    h->split = 0;
+    if (h->pipeline && !h->profiling && batch >= h->pipeline_min) {
+        // two halves on two streams (see gn_context.hpp); the child's stream is ordered after everything the caller
+        // has enqueued on this handle's stream, and both halves are complete when this call returns
+        GN_HIP(hipSetDevice(h->device));
+        if (!h->child) {
+            enlsip_gn_opts o{};
+            o.device = h->device; o.flags = h->flags; o.panel_width = 0; o.tile_rows = h->tile_rows; o.stream = nullptr;
+            int rc = enlsip_gn_create(&h->child, &o);
+            if (rc) { h->err = "could not create the second pipeline handle"; return rc; }
+            h->child->pipeline = false;
+            h->child->qrcp_mode = h->qrcp_mode;
+            h->child->factor_waves = h->factor_waves;
+        }
+        if (!h->ev_fork) GN_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        GN_HIP(hipEventRecord(h->ev_fork, h->stream));
+        GN_HIP(hipStreamWaitEvent(h->child->stream, h->ev_fork, 0));
+        const int64_t b0 = (batch + 1) / 2, b1 = batch - b0;
+        const int64_t kA = std::min(n, t);
+        enlsip_gn_handle c = h->child;
+        int rc1 = 0;
+        std::thread worker([&] {
+            (void)hipSetDevice(c->device);
+            rc1 = solve_dev(c, b1, m, n, t, dJ + b0 * strideJ, ldj, strideJ, drx + b0 * m, dAt ? dAt + b0 * strideAt : nullptr,
+                            ldat, strideAt, dcx ? dcx + b0 * t : nullptr, eps_rank, -1, -1, dp ? dp + b0 * n : nullptr,
+                            db ? db + b0 * t : nullptr, dd ? dd + b0 * m : nullptr, dinfo ? dinfo + b0 : nullptr,
+                            djpvtA ? (long long*)djpvtA + b0 * t : nullptr, djpvtL ? (long long*)djpvtL + b0 * kA : nullptr,
+                            djpvtJ2 ? (long long*)djpvtJ2 + b0 * n : nullptr);
+        });
+        const int rc0 = solve_dev(h, b0, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, -1, -1, dp, db,
+                                  dd, dinfo, (long long*)djpvtA, (long long*)djpvtL, (long long*)djpvtJ2);
+        worker.join();
+        if (rc0) return rc0;
+        if (rc1) { h->err = c->err; return rc1; }
+        h->split = b0;
+        return 0;
+    }
     return solve_dev(h, batch, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, -1, -1, dp, db,
                      dd, dinfo, (long long*)djpvtA, (long long*)djpvtL, (long long*)djpvtJ2);
 }

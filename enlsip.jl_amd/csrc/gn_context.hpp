@@ -71,6 +71,14 @@ struct enlsip_gn_context {
     void* h_sbinfo = nullptr;    // pinned mirror of sbInfo
     int cu_count = 256;
     enlsip_gn_context* sub = nullptr;   // handle for the stacked problem of the TSQR combine stage
+    // Two-stream pipelining of large batches (enlsip_gn_solve_batched_dev): the second half of the problems runs on
+    // a child handle (own stream + workspace) driven by a host thread, so the latency-bound kernels of one half
+    // overlap the bandwidth-bound kernels of the other.  Accessors route a problem index to the half that owns it.
+    enlsip_gn_context* child = nullptr;
+    bool pipeline = true;               // ENLSIP_GN_PIPELINE=0 disables
+    long long pipeline_min = 128;       // smallest batch that is split
+    long long split = 0;                // problems [split, batch) of the last solve live on `child` (0: not split)
+    hipEvent_t ev_fork = nullptr;
     long long tsqr_n2 = -1;             // n2 of the last tsqr_local on this handle
     int factor_waves = 8;   // waves per workgroup of k_caqr_factor (ENLSIP_GN_FACTOR_WAVES=4 selects the 4-wave form)
     int qrcp_mode = 2;   // 0 persistent (co-resident workgroups), 1 one launch per pivot step, 2 blocked with verified pivots

@@ -174,6 +174,38 @@ def test_batched_matches_single(solver):
             assert np.array_equal(jJ[k][:n - ref.rankA], ref.jpvtJ2)
 
 
+def test_pipelined_device_batch_matches_oracle(solver):
+    """A device-pointer batch >= 128 is split over two streams inside the library (second half on a child
+    handle): every problem must still match the oracle, and accessors must reach both halves."""
+    import torch
+    from enlsip_gn import FACTOR_J2
+    batch, m, n, t = 131, 96, 12, 2
+    dev = torch.device("cuda", 0)
+    Js, rxs, Ats, cxs, refs = [], [], [], [], []
+    for k in range(batch):
+        J, rx, A, cx = synth.make_problem(9000 + k, m, n, t)
+        Js.append(np.ascontiguousarray(J.T)); rxs.append(rx); Ats.append(np.ascontiguousarray(A)); cxs.append(cx)
+        refs.append(go.gn_subproblem(J, rx, A, cx))
+    dJ = torch.from_numpy(np.stack(Js)).to(dev)
+    drx = torch.from_numpy(np.stack(rxs)).to(dev)
+    dAt = torch.from_numpy(np.stack(Ats)).to(dev)
+    dcx = torch.from_numpy(np.stack(cxs)).to(dev)
+    dp = torch.zeros(batch, n, dtype=torch.float64, device=dev)
+    djJ = torch.zeros(batch, n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    solver.solve_batched_dev(batch, m, n, t, dJ.data_ptr(), m, m * n, drx.data_ptr(), dAt.data_ptr(), n, n * t,
+                             dcx.data_ptr(), dp=dp.data_ptr(), djJ=djJ.data_ptr())
+    p = dp.cpu().numpy()
+    jJ = djJ.cpu().numpy()
+    for k, ref in enumerate(refs):
+        assert rel(p[k], ref.p) <= TOL_P, k
+        assert np.array_equal(jJ[k][:n - ref.rankA], ref.jpvtJ2), k
+    for k in (0, 65, 66, 130):          # both sides of the split at (131 + 1) // 2 = 66
+        F = solver.factor(FACTOR_J2, prob=k)
+        assert np.array_equal(F.p, refs[k].jpvtJ2)
+        assert np.allclose(np.abs(F.diagR()), np.abs(np.diag(refs[k].F_J2.R)[: len(F.diagR())]), rtol=1e-9, atol=1e-12)
+
+
 def test_argument_errors(solver):
     from enlsip_gn import GNError
     J, rx, A, cx = synth.make_problem(1, 50, 10, 2)
