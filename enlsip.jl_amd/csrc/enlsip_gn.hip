@@ -106,7 +106,7 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     const long long per_dbl = P.sFA + P.sTauA + P.sFL + P.sTauL + P.sTA + P.sP1 + P.sB + P.sW + P.sT + P.sRt +
                               P.sTauJ + P.sZ + P.sVec + P.sM + P.sVb + P.sDiag + 2 * P.sVn + PB * PB;
     const long long per_i64 = P.sJA + P.sJL + P.sJJ;
-    const long long per_i32 = 6 * P.sQI;   // chosen + 2 x pos + 2 x colat + inblk
+    const long long per_i32 = 7 * P.sQI + 32;   // chosen + 2 x pos + 2 x colat + inblk + active list (n + 1 entries)
     const size_t bytes = (size_t)batch * (per_dbl * 8 + per_i64 * 8 + per_i32 * 4 + P.sCand * sizeof(QdCand)) +
                          (size_t)batch * (sizeof(ProbState) + sizeof(SbInfo)) + 8192;
     int rc = grow(h, h->ws, bytes);
@@ -138,6 +138,8 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     h->sbInfo = (void*)p;
     p += (((size_t)batch * sizeof(SbInfo) + 255) / 256) * 256;
     h->sbInblk = (int*)p;
+    p += (size_t)batch * P.sQI * 4;
+    h->sbAct = (int*)p;
     if (h->h_state_cap < (size_t)batch) {
         if (h->h_state) GN_HIP(hipHostFree(h->h_state));
         h->h_state = nullptr;
@@ -314,9 +316,9 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     q.cand = (QdCand*)h->qdCand; q.sCand = P.sCand; q.Gmax = P.qdGmax;
     q.jpvt = h->jpvtJ; q.sJ = P.sJJ; q.state = h->state;
     a.info = (SbInfo*)h->sbInfo; a.inblk = h->sbInblk; a.sIn = P.sQI; a.blkid = 0;
-    a.Tsb = h->sbT; a.sTsb = PB * PB;
+    a.Tsb = h->sbT; a.sTsb = PB * PB; a.act = h->sbAct; a.sAct = P.sQI + 32;
     const bool blk_update = !big_kp(kp_launch) && !getenv("ENLSIP_GN_SB_STEPWISE");   // MFMA block update (kp <= 512)
-    if (!blk_update) a.Tsb = nullptr;
+    if (!blk_update) { a.Tsb = nullptr; a.act = nullptr; }
     a.dbg = nullptr;
     if (getenv("ENLSIP_GN_SB_DEBUG")) {   // diagnostic: per-block phase stamps of problem 0 into the scratch buffer
         if (grow(h, h->scratch, 8 * 8 * 1024) == 0) {

@@ -68,6 +68,7 @@ struct enlsip_gn_context {
     double* sbT = nullptr;       // per problem: T factor of the current QRCP block (32 x 32)
     void* sbInfo = nullptr;      // SbInfo per problem (device)
     int* sbInblk = nullptr;      // per column block id (device)
+    int* sbAct = nullptr;        // per problem: columns the current block update touches (device)
     void* h_sbinfo = nullptr;    // pinned mirror of sbInfo
     int cu_count = 256;
     enlsip_gn_context* sub = nullptr;   // handle for the stacked problem of the TSQR combine stage

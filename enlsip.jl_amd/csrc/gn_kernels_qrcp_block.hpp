@@ -32,7 +32,9 @@ struct SbInfo {       // per problem, device
     int j0;           // first pivot step of the next block
     int s;            // steps done by the last select/factor launch
     int blk;          // id of the last block in which `s` steps were done
-    int pad;
+    int pad;          // first pivot step of that block
+    int nact;         // columns the block update has to touch (list in `act`): still trailing, not a candidate, + the rhs
+    int pad2[3];
 };
 
 struct SbArgs {
@@ -41,6 +43,7 @@ struct SbArgs {
     int* inblk;       long long sIn;    // per physical column: id of the last block it was a candidate in
     int blkid;
     double* Tsb;      long long sTsb;   // per problem: dlarft T (32 x 32, column-major) of the last block's reflectors
+    int* act;         long long sAct;   // per problem: compact list of the columns the block update touches
     long long* dbg;   // optional (diagnostic builds): 8 realtime stamps per block of problem prob0
 };
 
@@ -371,8 +374,36 @@ __global__ __launch_bounds__(1024) void k_sb_factor(SbArgs a) {
     }
     stamp(4);
     if (a.dbg && tid == 0 && prob == a.q.prob0) a.dbg[a.blkid * 8 + 5] = s;
+    // compact list of the columns the block update has to touch: trailing at block start and not a candidate of
+    // this block (candidates received every reflector here), followed by the carried right-hand side
+    int nact = 0;
+    if (a.act != nullptr) {
+        int* act = a.act + prob * a.sAct;
+        __shared__ int wtot[16];
+        const int per = (n2 + 15) / 16;                     // columns per wave, processed 64 at a time
+        int cnt = 0;
+        for (int c0 = w * per; c0 < (w + 1) * per && c0 < n2; c0 += WAVE) {
+            const int c = c0 + ln;
+            const bool f = (c < (w + 1) * per) && (c < n2) && (L.posk[c] != 0x7fffffff) && (L.rankl[c] >= K);
+            cnt += __popcll(__ballot(f));
+        }
+        if (ln == 0) wtot[w] = cnt;
+        __syncthreads();
+        int off = 0;
+        for (int q = 0; q < w; ++q) off += wtot[q];
+        for (int q = 0; q < 16; ++q) nact += wtot[q];
+        for (int c0 = w * per; c0 < (w + 1) * per && c0 < n2; c0 += WAVE) {
+            const int c = c0 + ln;
+            const bool f = (c < (w + 1) * per) && (c < n2) && (L.posk[c] != 0x7fffffff) && (L.rankl[c] >= K);
+            const unsigned long long bal = __ballot(f);
+            if (f) act[off + __popcll(bal & ((1ull << ln) - 1ull))] = c;
+            off += __popcll(bal);
+        }
+        if (tid == 0) act[nact] = n2;
+        nact += 1;
+    }
     if (tid == 0) {
-        SbInfo o = {j0 + s, s, a.blkid, j0};   // pad carries the block's first step for the update kernel
+        SbInfo o = {j0 + s, s, a.blkid, j0, nact, {0, 0, 0}};   // pad carries the block's first step for the update kernel
         *info = o;
     }
 }
@@ -554,28 +585,24 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
     const SbInfo info = a.info[prob];
     if (info.blk != a.blkid || info.s == 0) return;     // this problem did no step in this block
     const int jb = info.pad, s = info.s;
-    const int cb0 = blockIdx.x * 32;
-    if (cb0 >= ctot) return;
+    const int cb0 = blockIdx.x * 32;                    // position in the list of active columns
+    const int nact = info.nact;
+    if (cb0 >= nact) return;
+    (void)ctot;
     const int ln = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
     const int lr = ln & 15, lq = ln >> 4;
-    const int* chosen = a.q.chosen + prob * a.q.sI;
-    const int* inblk = a.inblk + prob * a.sIn;
-    // activity of the block's 32 columns (identical in every wave)
-    bool act = false;
-    if (ln < 32) {
-        const int c = cb0 + ln;
-        act = (c == n2) || (c < n2 && chosen[c] < 0 && inblk[c] != a.blkid);
-    }
-    const unsigned actbits = (unsigned)(__ballot(act) & 0xffffffffull);
-    if (actbits == 0u) return;
-    unsigned vmask = 0u, smask = 0u;
+    const int* actl = a.act + prob * a.sAct;
+    unsigned vmask = 0u;
+    unsigned coff[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const int cl = 16 * (b >> 2) + 4 * (b & 3) + lq;
-        vmask |= (cb0 + cl < ctot) ? (1u << b) : 0u;
-        smask |= ((actbits >> cl) & 1u) ? (1u << b) : 0u;
+        const int idx = cb0 + 16 * (b >> 2) + 4 * (b & 3) + lq;
+        const bool ok = idx < nact;
+        vmask |= ok ? (1u << b) : 0u;
+        coff[b] = (unsigned)actl[ok ? idx : cb0] * (unsigned)a.q.ldr * 8u;   // invalid slots re-read a valid column, masked out
     }
+    const unsigned smask = vmask;
     V4Ctx c;
     c.Wm = a.q.Vb + prob * a.q.sVb;
     c.C = a.q.M + prob * a.q.sM;
@@ -592,8 +619,8 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc8[b] = 0.0;
     SbPost post{acc8, stage[0], w, lr, lq, s + d};
-    if (ctot - cb0 <= 16) v4_dispatch<8, false, false, 1, true, SbPost>(c, w, ngw, stage, W2l, vmask, smask, post);
-    else v4_dispatch<8, false, false, 2, true, SbPost>(c, w, ngw, stage, W2l, vmask, smask, post);
+    if (nact - cb0 <= 16) v4_dispatch<8, false, false, 1, true, SbPost, true>(c, w, ngw, stage, W2l, vmask, smask, post, coff);
+    else v4_dispatch<8, false, false, 2, true, SbPost, true>(c, w, ngw, stage, W2l, vmask, smask, post, coff);
 
     // per-column sums of squares: reduce over the 16 row-pair lanes, one writer per (wave, column)
 #pragma unroll
@@ -606,9 +633,9 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
         if (lr == 0) ssq[w][16 * (b >> 2) + 4 * (b & 3) + lq] = x;
     }
     __syncthreads();
-    if (w != 0 || ln >= 32) return;
-    const int cc = cb0 + ln;
-    if (!((actbits >> ln) & 1u) || cc >= n2) return;
+    if (w != 0 || ln >= 32 || cb0 + ln >= nact) return;
+    const int cc = actl[cb0 + ln];
+    if (cc >= n2) return;                               // the carried right-hand side has no norm
     double* vn1 = a.q.vn1 + prob * a.q.sVn;
     double* vn2 = a.q.vn2 + prob * a.q.sVn;
     const double tol3z = 1.4901161193847656e-08;

@@ -82,9 +82,12 @@ struct V4NoPost {         // default post-update hook: nothing
 //         column holds valid data / column is written back.
 // post(g, fr): called with the updated fragments of unit g (fr[p][ct][r] = row pair element p of column
 //         16 ct + lq + 4 r) before they are stored.
-template <int RPL, bool TRI, bool CFULL, int NGW, int NCT, bool RMASK = false, class Post = V4NoPost>
+// GATHER = true: the block's 32 columns are arbitrary columns of C: coff[4 ct + r] is this lane's byte offset of
+//         column (16 ct + lq + 4 r) from c.C (the blocked pivoted QR updates only its still-active columns).
+template <int RPL, bool TRI, bool CFULL, int NGW, int NCT, bool RMASK = false, class Post = V4NoPost, bool GATHER = false>
 __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*stage)[V4_STAGE], double* W2l,
-                                        const unsigned vmask = ~0u, const unsigned smask = ~0u, const Post& post = Post()) {
+                                        const unsigned vmask = ~0u, const unsigned smask = ~0u, const Post& post = Post(),
+                                        const unsigned* coff = nullptr) {
     const int ln = lane_id();
     const int lr = ln & 15, lq = ln >> 4;
     const int it2 = w >> 1, ct2 = w & 1;             // W2 tile produced by this wave in the reduction step
@@ -97,6 +100,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         return c.r0 + (c.gblk0 + (w + 4 * g)) * c.S;
     };
     auto cptr = [&](int g, int ct, int r) -> double* {
+        if (GATHER) return (double*)((char*)(c.C + rowu(g)) + (coff[4 * ct + r] + 16u * (unsigned)lr));
         double* ub = c.C + (size_t)(c.cb0 + 16 * ct + 4 * r) * c.ldw + rowu(g);      // uniform
         return (double*)((char*)ub + lane_byte);
     };
@@ -304,16 +308,17 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     }
 }
 
-template <int RPL, bool TRI, bool CFULL, int NCT, bool RMASK = false, class Post = V4NoPost>
+template <int RPL, bool TRI, bool CFULL, int NCT, bool RMASK = false, class Post = V4NoPost, bool GATHER = false>
 __device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, double (*stage)[V4_STAGE], double* W2l,
-                                            const unsigned vmask = ~0u, const unsigned smask = ~0u, const Post& post = Post()) {
+                                            const unsigned vmask = ~0u, const unsigned smask = ~0u, const Post& post = Post(),
+                                            const unsigned* coff = nullptr) {
     constexpr int NG = RPL / 2;
     // every variant executes exactly two workgroup barriers, so waves of one workgroup may take different ones
-    if (ngw >= NG) v4_body<RPL, TRI, CFULL, NG, NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
-    else if (NG > 3 && ngw == 3) v4_body<RPL, TRI, CFULL, (NG > 3 ? 3 : 0), NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
-    else if (NG > 2 && ngw == 2) v4_body<RPL, TRI, CFULL, (NG > 2 ? 2 : 0), NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
-    else if (NG > 1 && ngw == 1) v4_body<RPL, TRI, CFULL, (NG > 1 ? 1 : 0), NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
-    else v4_body<RPL, TRI, CFULL, 0, NCT, RMASK, Post>(c, w, stage, W2l, vmask, smask, post);
+    if (ngw >= NG) v4_body<RPL, TRI, CFULL, NG, NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
+    else if (NG > 3 && ngw == 3) v4_body<RPL, TRI, CFULL, (NG > 3 ? 3 : 0), NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
+    else if (NG > 2 && ngw == 2) v4_body<RPL, TRI, CFULL, (NG > 2 ? 2 : 0), NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
+    else if (NG > 1 && ngw == 1) v4_body<RPL, TRI, CFULL, (NG > 1 ? 1 : 0), NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
+    else v4_body<RPL, TRI, CFULL, 0, NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
 }
 
 template <int RPL, bool TRI>
