@@ -15,6 +15,7 @@
 #include "gn_kernels_final.hpp"
 #include "gn_kernels_q1.hpp"
 #include "gn_kernels_q1_mfma.hpp"
+#include "gn_kernels_q1_v2.hpp"
 #include "gn_kernels_update_v4.hpp"
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_qrcp_dist.hpp"
@@ -475,7 +476,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         qa.W = h->W; qa.sW = P.sW; qa.state = h->state;
         qa.prob0 = 0;
         if (h->flags & ENLSIP_GN_UPDATE_REFLECTORS) launch_jq1(qa, (int)batch, s);   // plain-FMA A/B partner
-        else launch_jq1_mfma(qa, (int)batch, s);
+        else if (getenv("ENLSIP_GN_JQ1_V1") || !launch_jq1_v2(qa, (int)batch, s)) launch_jq1_mfma(qa, (int)batch, s);
         mark(2);
         // 3. CAQR of [J2 | d]
         rc = run_caqr(h, n2_launch);
