@@ -57,6 +57,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
     __shared__ double vsh[2][64 * RPL];
     __shared__ double taush[PB];
     __shared__ double gsh[PB][PB + 1];
+    __shared__ double tsh[PB][PB + 1];
 
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
     if (w == 0) {
         double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
         if (ln < PB) {
-            // row ln of T lives in LDS (vsh is free now): no register array, so the kernel keeps its
-            // register budget for the tile and two workgroups fit a CU
-            double* trow = &vsh[0][0] + ln * (PB + 1);
+            // row ln of T lives in LDS: no register array, so the kernel keeps its register budget for the tile
+            // (its own 32 x 33 image: the reflector buffers vsh hold only 128 RPL doubles)
+            double* trow = &tsh[ln][0];
             for (int j = 0; j < PB; ++j) {
                 const double tj = taush[j];
                 double s = 0.0;

@@ -78,6 +78,21 @@ def test_shapes(m, n, t, solver):
     compare(out, ref, m, n)
 
 
+@pytest.mark.parametrize("m,n,t", [(300, 40, 5), (777, 45, 7), (1500, 70, 5), (2048, 128, 16), (4096, 96, 32)])
+@pytest.mark.parametrize("flags", [0, 2])
+def test_tile_rows_256(m, n, t, flags):
+    """The 256-row CAQR tile (one more tree level, RPL = 4 kernel instantiations) against the oracle, with the MFMA
+    and with the reflector-by-reflector trailing update."""
+    from enlsip_gn import GNSolver
+    s = GNSolver(device=0, flags=flags, tile_rows=256)
+    try:
+        J, rx, A, cx = synth.make_problem(700 + m + n, m, n, t)
+        ref = go.gn_subproblem(J, rx, A, cx)
+        compare(s.solve(J, rx, A, cx), ref, m, n)
+    finally:
+        s.close()
+
+
 def test_mfma_and_reflector_updates_agree(solver, solver_refl):
     J, rx, A, cx = synth.make_problem(321, 3000, 200, 10)
     a = solver.solve(J, rx, A, cx)
