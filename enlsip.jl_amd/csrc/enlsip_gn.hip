@@ -21,6 +21,7 @@
 #include "gn_kernels_qrcp_dist.hpp"
 #include "gn_kernels_qrcp_persist.hpp"
 #include "gn_kernels_qrcp_block.hpp"
+#include "gn_kernels_qrcp_block_reg.hpp"
 
 using namespace gn;
 
@@ -320,6 +321,7 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     a.Tsb = h->sbT; a.sTsb = PB * PB; a.act = h->sbAct; a.sAct = P.sQI + 32;
     const bool blk_update = !big_kp(kp_launch) && !getenv("ENLSIP_GN_SB_STEPWISE");   // MFMA block update (kp <= 512)
     if (!blk_update) { a.Tsb = nullptr; a.act = nullptr; }
+    const bool reg_factor = !big_kp(kp_launch) && !getenv("ENLSIP_GN_SB_LDS");   // candidates in registers (kp <= 512)
     a.dbg = nullptr;
     if (getenv("ENLSIP_GN_SB_DEBUG")) {   // diagnostic: per-block phase stamps of problem 0 into the scratch buffer
         if (grow(h, h->scratch, 8 * 8 * 1024) == 0) {
@@ -349,7 +351,10 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
                 hipLaunchKernelGGL(k_sb_factor<16>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
                 hipLaunchKernelGGL(k_sb_update<16>, ugrid, dim3(256), 0, s, a);
             } else {
-                hipLaunchKernelGGL(k_sb_factor<8>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
+                if (!reg_factor) hipLaunchKernelGGL(k_sb_factor<8>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
+                else if (kp_launch <= 256) hipLaunchKernelGGL((k_sb_factor_reg<4, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
+                else if (kp_launch <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((k_sb_factor_reg<8, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
                 if (blk_update) hipLaunchKernelGGL(k_sb_update_blk, ugrid, dim3(256), 0, s, a);
                 else hipLaunchKernelGGL(k_sb_update<8>, ugrid, dim3(256), 0, s, a);
             }

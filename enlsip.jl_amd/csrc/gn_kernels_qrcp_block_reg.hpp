@@ -1,0 +1,381 @@
+// Select/factor kernel of the blocked pivoted QR (gn_kernels_qrcp_block.hpp), second form: the K <= 64
+// candidate columns of a block live in REGISTERS (16 waves x 4 columns, lane = row), not in LDS.
+//
+// The first form keeps the candidates in an LDS slab and moves every candidate through LDS <-> registers once
+// per pivot step: at K = 64 and 448 rows that is 459 KB of LDS traffic per step (~2.5 us at the LDS rates of
+// this chip) and the slab limits K to 32 while the rows are long.  Here a step touches LDS only for the
+// reflector broadcast (one column), exactly like the CAQR panel kernel:
+//   * every wave finds the pivot among the candidates' norms (LDS scalars, identical result everywhere);
+//   * the wave that owns the pivot column builds the reflector from its registers and broadcasts it;
+//   * every wave applies it to its 4 columns with one batched transposed reduction (wave_allsum4), downdates
+//     their norms (dlaqp2 rule), and the dot products with the columns retired earlier in the block are the Gram
+//     entries of the block's T factor — no separate pass over the reflectors.
+// Pivot rule, certainty test against the best outside norm, logical positions and the write-back are those of
+// the first form (same SbLds bookkeeping arrays; the slab is simply unused).
+#pragma once
+#include "gn_kernels_qrcp_block.hpp"
+
+namespace gn {
+
+struct SbRegLds {             // everything of SbLds except the slab
+    double valk[SB_NMAX];
+    int posk[SB_NMAX];
+    int pos_l[SB_NMAX];
+    int colat_l[SB_NMAX];
+    double cvn1[2][SB_KMAX], cvn2[SB_KMAX];
+    int ccol[SB_KMAX], cpos[2][SB_KMAX];
+    int rankl[SB_NMAX];
+    double taul[SB_KMAX], betal[SB_KMAX];
+    double gram[32 * 33];
+    double tmat[32 * 33];
+    int tslot[32];
+    double vsh[2][512];       // reflector broadcast, double-buffered by step parity
+    double tau_s[2];
+    int wtot[16];
+    double bval;
+    int bpos;
+    int K;
+};
+
+// RPL: rows of the block kp - j0 <= 64 * RPL.  NWV waves hold NCW = 64 / NWV candidate columns each.  With 16 waves
+// (128 registers per lane) the compiler spills inside the step loop and a step costs 7.7 us; 8 waves x 8 columns
+// run spill-free.
+template <int RPL, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_sb_factor_reg(SbArgs a) {
+    constexpr int NCW = SB_KMAX / NWV;
+    constexpr int NT = 64 * NWV;
+    __shared__ SbRegLds L;
+    const int prob = blockIdx.x + a.q.prob0;
+    const ProbState st = a.q.state[prob];
+    const int kp = st.kp, n2 = st.n2;
+    SbInfo* info = a.info + prob;
+    const int j0 = info->j0;
+    if (j0 >= kp) return;
+    const int tid = threadIdx.x, ln = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const int rows = kp - j0;
+    double* M = a.q.M + prob * a.q.sM;
+    double* vn1 = a.q.vn1 + prob * a.q.sVn;
+    double* vn2 = a.q.vn2 + prob * a.q.sVn;
+    int* chosen = a.q.chosen + prob * a.q.sI;
+    int* pos = a.q.pos + prob * 2 * a.q.sI;       // parity-0 arrays only
+    int* colat = a.q.colat + prob * 2 * a.q.sI;
+    const double tol3z = 1.4901161193847656e-08;
+
+    auto stamp = [&](int i) {
+        if (a.dbg && tid == 0 && prob == a.q.prob0) a.dbg[a.blkid * 8 + i] = (long long)__builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    // ---- 1. keys of the trailing columns --------------------------------------------------------
+    for (int c = tid; c < n2; c += NT) {
+        const bool tr = chosen[c] < 0;
+        L.valk[c] = tr ? vn1[c] : -1.0;
+        const int p = pos[c];
+        L.posk[c] = tr ? p : 0x7fffffff;
+        L.pos_l[c] = p;
+        L.colat_l[c] = colat[c];
+        L.rankl[c] = 0;
+    }
+    const int ntrail = n2 - j0;
+    int K = SB_KMAX < ntrail ? SB_KMAX : ntrail;
+    if (tid == 0) {
+        L.K = K;
+        L.bval = -1.0;     // no outside column unless a rank == K exists
+        L.bpos = 0x7fffffff;
+    }
+    __syncthreads();
+    // ---- 2. rank by (norm desc, position asc); ranks < K are the candidates, rank K is the bound ----------
+    {
+        const int parts = (2 * n2 <= NT) ? 2 : 1;      // two threads per column only when that still is one round
+        const int per = (n2 + parts - 1) / parts;
+        for (int e = tid; e < n2 * parts; e += NT) {
+            const int c = (parts == 2) ? (e >> 1) : e;
+            const int part = (parts == 2) ? (e & 1) : 0;
+            const double v = L.valk[c];
+            const int p = L.posk[c];
+            if (p == 0x7fffffff) continue;
+            int rank = 0;
+            const int k1 = (part + 1) * per < n2 ? (part + 1) * per : n2;
+            for (int k = part * per; k < k1; ++k) {
+                const double vk = L.valk[k];
+                const int pk = L.posk[k];
+                rank += (pk != 0x7fffffff && (vk > v || (vk == v && pk < p))) ? 1 : 0;
+            }
+            if (rank) atomicAdd(&L.rankl[c], rank);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < n2; c += NT) {
+        const int p = L.posk[c];
+        if (p == 0x7fffffff) continue;
+        const int rank = L.rankl[c];
+        if (rank < K) {
+            L.ccol[rank] = c;
+            L.cpos[0][rank] = p;
+            L.cvn1[0][rank] = L.valk[c];
+            L.cvn2[rank] = vn2[c];
+            a.inblk[prob * a.sIn + c] = a.blkid;
+        } else if (rank == K) {
+            L.bval = L.valk[c];
+            L.bpos = p;
+        }
+    }
+    __syncthreads();
+    stamp(1);
+    // ---- 3. candidate columns -> registers: slot k = w + NWV cc, local row ln + 64 i (row j0 + .. of M) --------
+    double x[NCW][RPL];
+#pragma unroll
+    for (int cc = 0; cc < NCW; ++cc) {
+        const int k = w + NWV * cc;
+        const int c = (k < K) ? L.ccol[k] : 0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = ln + 64 * i;
+            x[cc][i] = (k < K && r < rows) ? M[(j0 + r) + (size_t)c * a.q.ldr] : 0.0;
+        }
+    }
+    // value of local row r < 64 (wave-uniform) of column x[cc]: a block makes at most 64 steps, so its pivot rows all
+    // sit in register 0
+    auto row_of = [&](const double (&xc)[RPL], int r) -> double { return wave_bcast(xc[0], r); };
+    stamp(2);
+    // ---- 4. pivot steps -------------------------------------------------------------------------------------
+    const int smax = (a.Tsb != nullptr) ? 32 - (j0 & 1) : SB_KMAX;   // the blocked update applies <= 32 reflectors at once
+    int s = 0;
+    for (;; ++s) {
+        // opaque per-iteration copies of the lane / wave ids: without them loop-invariant code motion hoists every row
+        // mask and LDS address of the unrolled columns out of the loop and spills them
+        int lnl = ln, wl = w;
+        asm volatile("" : "+v"(lnl));
+        asm volatile("" : "+s"(wl));
+        const int j = j0 + s;
+        if (j >= kp || s >= smax) break;
+        const int rd = s & 1, wr = rd ^ 1;
+        // every wave finds the pivot among the active candidates (identical result in all waves)
+        double bv = -1.0;
+        int bp = 0x7fffffff, bk = -1;
+        if (lnl < K && L.cpos[rd][lnl] >= 0) {
+            bv = L.cvn1[rd][lnl];
+            bp = L.cpos[rd][lnl];
+            bk = lnl;
+        }
+        const ArgMax am = wave_argmax(bv, bp, bk);
+        // certain iff it beats every column left outside (their current norms are <= bval); the first
+        // step of a block is always certain: rank 0 is the global maximum
+        if (!(am.idx >= 0 && (s == 0 || am.val > L.bval))) break;
+        const int ci = am.idx, q = am.pos;
+        // the owner of the pivot column builds the reflector (rows > s of the column; pivot entry in local row s)
+        if (wl == ci % NWV) {
+#pragma unroll
+            for (int cc = 0; cc < NCW; ++cc) {
+                if (cc == ci / NWV) {
+                    double xn2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i)
+                        if (lnl + 64 * i > s) xn2 += x[cc][i] * x[cc][i];
+                    xn2 = wave_allsum(xn2);
+                    const double alpha = row_of(x[cc], s);
+                    const Reflector h = make_reflector(alpha, xn2);
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) {
+                        const int r = lnl + 64 * i;
+                        const double v = (r > s) ? x[cc][i] * h.scale : (r == s ? 1.0 : 0.0);
+                        L.vsh[rd][r] = v;
+                        if (r > s) x[cc][i] = v;           // the retired column keeps its reflector below the diagonal
+                        if (r == s) x[cc][i] = h.beta;
+                    }
+                    if (lnl == 0) {
+                        L.taul[ci] = h.tau;
+                        L.betal[ci] = h.beta;
+                        L.tau_s[rd] = h.tau;
+                        if (s < 32) L.tslot[s] = ci;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        double v[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) v[i] = L.vsh[rd][lnl + 64 * i];
+        const double tj = L.tau_s[rd];
+        double dot[NCW], ds[NCW];
+#pragma unroll
+        for (int cc = 0; cc < NCW; ++cc) {
+            dot[cc] = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) dot[cc] += x[cc][i] * v[i];
+        }
+        wave_allsumN(dot, ds);
+        // apply the reflector to the active candidates; the dot products with the columns retired earlier in this
+        // block (step a = -1 - cpos - j0 < s) are v_a' v_s, the Gram entries of the T factor
+        double ajc4[NCW];
+        unsigned actm = 0u;
+#pragma unroll
+        for (int cc = 0; cc < NCW; ++cc) {
+            const int k = wl + NWV * cc;
+            ajc4[cc] = 0.0;
+            if (k >= K || k == ci) continue;
+            const int pk = L.cpos[rd][k];
+            if (pk >= 0) {
+                if (tj != 0.0) {
+                    const double wd = tj * ds[cc];
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) x[cc][i] -= wd * v[i];
+                }
+                ajc4[cc] = row_of(x[cc], s);
+                actm |= 1u << cc;
+            } else {
+                const int aa = (-1 - pk) - j0;
+                if (lnl == 0 && aa >= 0 && aa < 32 && s < 32) L.gram[aa * 33 + s] = ds[cc];
+            }
+        }
+        // dlaqp2 norm downdate of the wave's active columns as ONE instruction stream: lane u < NCW <-> column u
+        {
+            const int u = lnl & (NCW - 1);
+            const int ku = wl + NWV * u;
+            const bool mine = (lnl < NCW) && ((actm >> u) & 1u);
+            double ajc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NCW; ++cc) ajc = (u == cc) ? ajc4[cc] : ajc;
+            double o1 = mine ? L.cvn1[rd][ku] : 0.0;
+            const double o2 = mine ? L.cvn2[ku] : 1.0;
+            bool need = false;
+            if (mine && o1 != 0.0) {
+                double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
+                temp = temp > 0.0 ? temp : 0.0;
+                const double qq = o1 / o2;
+                const double temp2 = temp * qq * qq;
+                if (temp2 <= tol3z) need = true;
+                else o1 = o1 * sqrt(temp);
+            }
+            unsigned nm = (unsigned)(__ballot(need) & ((1ull << NCW) - 1ull));
+            while (nm) {                                   // rare: recompute the partial norm from the column
+                const int uu = __ffs((int)nm) - 1;
+                nm &= nm - 1;
+                double sq = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < NCW; ++cc)
+                    if (cc == uu) {
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i)
+                            if (lnl + 64 * i > s) sq += x[cc][i] * x[cc][i];
+                    }
+                sq = wave_allsum(sq);
+                if (lnl == uu) {
+                    o1 = (j + 1 < kp) ? sqrt(sq) : 0.0;
+                    L.cvn2[ku] = o1;
+                }
+            }
+            if (mine) L.cvn1[wr][ku] = o1;
+        }
+        // position bookkeeping (wave 0): pivot at position q <-> column cj that sat at position j
+        if (wl == 0) {
+            const int pc = L.ccol[ci];
+            const int cj = L.colat_l[j];
+            const bool match = (lnl < K) && (L.ccol[lnl] == cj) && (cj != pc);
+            const unsigned long long mb = __ballot(match);
+            const int slot = mb ? (__ffsll((long long)mb) - 1) : -1;
+            if (lnl < K) {
+                const int old = L.cpos[rd][lnl];
+                L.cpos[wr][lnl] = (lnl == ci) ? (-1 - j) : ((lnl == slot) ? q : old);
+            }
+            if (lnl == 0) {
+                L.colat_l[j] = pc;
+                L.colat_l[q] = cj;
+                L.pos_l[cj] = q;
+                L.pos_l[pc] = j;
+            }
+        }
+        __syncthreads();
+    }
+    const int fin = s & 1;   // buffer holding the state after the last completed step
+    stamp(3);
+    // ---- 4b. T factor (dlarft, forward / columnwise) from the Gram entries gathered during the steps -------------
+    if (a.Tsb != nullptr && w == 0) {
+        double* T = a.Tsb + prob * a.sTsb;
+        if (ln < 32) {
+            double* trow = L.tmat + ln * 33;
+            for (int b = 0; b < 32; ++b) {
+                double tv = 0.0;
+                if (b < s && ln <= b) {
+                    const double tb = L.taul[L.tslot[b]];
+                    if (ln == b) tv = tb;
+                    else {
+                        double acc = 0.0;
+                        for (int l = ln; l < b; ++l) acc += trow[l] * L.gram[l * 33 + b];
+                        tv = -tb * acc;
+                    }
+                }
+                trow[b] = tv;
+                T[ln + b * 32] = tv;
+            }
+        }
+    }
+    stamp(4);
+    if (a.dbg && tid == 0 && prob == a.q.prob0) a.dbg[a.blkid * 8 + 5] = s;
+    // ---- 5. write back --------------------------------------------------------------------------------------
+#pragma unroll
+    for (int cc = 0; cc < NCW; ++cc) {
+        const int k = w + NWV * cc;
+        if (k >= K) continue;
+        const int c = L.ccol[k];
+        const int pk = L.cpos[fin][k];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = ln + 64 * i;
+            if (r < rows) M[(j0 + r) + (size_t)c * a.q.ldr] = x[cc][i];
+        }
+        if (pk < 0) {   // retired at step jr: rows below the diagonal hold the reflector
+            const int jr = -1 - pk;
+            double* Vb = a.q.Vb + prob * a.q.sVb;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const int r = ln + 64 * i;
+                if (r > jr - j0 && r < rows) Vb[(j0 + r) + (size_t)jr * a.q.ldr] = x[cc][i];
+            }
+            if (ln == 0) {
+                a.q.diag[prob * a.q.sDiag + jr] = L.betal[k];
+                a.q.tau[prob * a.q.sTau + jr] = L.taul[k];
+                chosen[c] = jr;
+            }
+        } else if (ln == 0) {
+            vn1[c] = L.cvn1[fin][k];
+            vn2[c] = L.cvn2[k];
+        }
+    }
+    for (int c = tid; c < n2; c += NT) {
+        pos[c] = L.pos_l[c];
+        colat[c] = L.colat_l[c];
+    }
+    // compact list of the columns the block update has to touch (see the first form)
+    int nact = 0;
+    if (a.act != nullptr) {
+        int* act = a.act + prob * a.sAct;
+        const int per = (n2 + NWV - 1) / NWV;
+        int cnt = 0;
+        for (int c0 = w * per; c0 < (w + 1) * per && c0 < n2; c0 += WAVE) {
+            const int c = c0 + ln;
+            const bool f = (c < (w + 1) * per) && (c < n2) && (L.posk[c] != 0x7fffffff) && (L.rankl[c] >= K);
+            cnt += __popcll(__ballot(f));
+        }
+        if (ln == 0) L.wtot[w] = cnt;
+        __syncthreads();
+        int off = 0;
+        for (int qq = 0; qq < w; ++qq) off += L.wtot[qq];
+        for (int qq = 0; qq < NWV; ++qq) nact += L.wtot[qq];
+        for (int c0 = w * per; c0 < (w + 1) * per && c0 < n2; c0 += WAVE) {
+            const int c = c0 + ln;
+            const bool f = (c < (w + 1) * per) && (c < n2) && (L.posk[c] != 0x7fffffff) && (L.rankl[c] >= K);
+            const unsigned long long bal = __ballot(f);
+            if (f) act[off + __popcll(bal & ((1ull << ln) - 1ull))] = c;
+            off += __popcll(bal);
+        }
+        if (tid == 0) act[nact] = n2;
+        nact += 1;
+    }
+    if (tid == 0) {
+        SbInfo o = {j0 + s, s, a.blkid, j0, nact, {0, 0, 0}};
+        *info = o;
+    }
+}
+
+}  // namespace gn
