@@ -84,40 +84,55 @@ __global__ __launch_bounds__(64 * NWV) void k_sb_factor_reg(SbArgs a) {
         L.bpos = 0x7fffffff;
     }
     __syncthreads();
-    // ---- 2. rank by (norm desc, position asc); ranks < K are the candidates, rank K is the bound ----------
+    // ---- 2. order the trailing columns by (norm desc, position asc): bitonic sort of (norm, position, column) in
+    // LDS (the Gram / T images are free now); rank r < K = candidate slot r, rank K = best outside column = the bound
     {
-        const int parts = (2 * n2 <= NT) ? 2 : 1;      // two threads per column only when that still is one round
-        const int per = (n2 + parts - 1) / parts;
-        for (int e = tid; e < n2 * parts; e += NT) {
-            const int c = (parts == 2) ? (e >> 1) : e;
-            const int part = (parts == 2) ? (e & 1) : 0;
-            const double v = L.valk[c];
-            const int p = L.posk[c];
-            if (p == 0x7fffffff) continue;
-            int rank = 0;
-            const int k1 = (part + 1) * per < n2 ? (part + 1) * per : n2;
-            for (int k = part * per; k < k1; ++k) {
-                const double vk = L.valk[k];
-                const int pk = L.posk[k];
-                rank += (pk != 0x7fffffff && (vk > v || (vk == v && pk < p))) ? 1 : 0;
-            }
-            if (rank) atomicAdd(&L.rankl[c], rank);
+        int P = 64;
+        while (P < n2) P <<= 1;                            // <= 1024
+        double* sv = L.gram;                               // 1024 doubles
+        int* sp = reinterpret_cast<int*>(L.gram + 1024);   // 1024 ints
+        int* sc = sp + 1024;                               // 1024 ints  (gram + tmat = 2112 doubles >= 2048)
+        for (int e = tid; e < P; e += NT) {
+            const bool in = e < n2;
+            sv[e] = in ? L.valk[e] : -2.0;
+            sp[e] = in ? L.posk[e] : 0x7fffffff;
+            sc[e] = in ? e : -1;
         }
-    }
-    __syncthreads();
-    for (int c = tid; c < n2; c += NT) {
-        const int p = L.posk[c];
-        if (p == 0x7fffffff) continue;
-        const int rank = L.rankl[c];
-        if (rank < K) {
-            L.ccol[rank] = c;
-            L.cpos[0][rank] = p;
-            L.cvn1[0][rank] = L.valk[c];
-            L.cvn2[rank] = vn2[c];
-            a.inblk[prob * a.sIn + c] = a.blkid;
-        } else if (rank == K) {
-            L.bval = L.valk[c];
-            L.bpos = p;
+        __syncthreads();
+        for (int kk = 2; kk <= P; kk <<= 1) {
+            for (int jx = kk >> 1; jx > 0; jx >>= 1) {
+                for (int t = tid; t < (P >> 1); t += NT) {
+                    const int i = ((t & ~(jx - 1)) << 1) | (t & (jx - 1));
+                    const int l = i | jx;
+                    const bool up = (i & kk) == 0;          // better-first in this half
+                    const double va = sv[i], vb = sv[l];
+                    const int pa = sp[i], pb = sp[l];
+                    const bool b_better = vb > va || (vb == va && pb < pa);
+                    if (b_better == up) {
+                        const int ca = sc[i], cb = sc[l];
+                        sv[i] = vb; sv[l] = va;
+                        sp[i] = pb; sp[l] = pa;
+                        sc[i] = cb; sc[l] = ca;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int r = tid; r < n2; r += NT) {
+            const int c = sc[r];
+            const int p = sp[r];
+            if (c < 0 || p == 0x7fffffff) continue;         // padding / not a trailing column
+            L.rankl[c] = r;
+            if (r < K) {
+                L.ccol[r] = c;
+                L.cpos[0][r] = p;
+                L.cvn1[0][r] = sv[r];
+                L.cvn2[r] = vn2[c];
+                a.inblk[prob * a.sIn + c] = a.blkid;
+            } else if (r == K) {
+                L.bval = sv[r];
+                L.bpos = p;
+            }
         }
     }
     __syncthreads();
