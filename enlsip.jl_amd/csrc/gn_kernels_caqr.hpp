@@ -57,7 +57,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
     __shared__ double vsh[2][64 * RPL];
     __shared__ double taush[PB];
     __shared__ double gsh[PB][PB + 1];
-    __shared__ double tsh[PB][PB + 1];
 
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
@@ -167,13 +166,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
     if (w == 0) {
         double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
         if (ln < PB) {
-            // row ln of T lives in LDS: no register array, so the kernel keeps its register budget for the tile
-            // (its own 32 x 33 image: the reflector buffers vsh hold only 128 RPL doubles)
-            double* trow = &tsh[ln][0];
+            // row ln of T in registers, loops fully unrolled and branch-free: T is upper triangular, so trow[l] = 0
+            // for l < ln and the plain sum over l < j is the dlarft sum over ln <= l < j; gsh / taush are zero where no
+            // reflector exists.  (The tile registers are dead here.  A lane-bounded loop over LDS rows cost ~20 us.)
+            double trow[PB];
+#pragma unroll
             for (int j = 0; j < PB; ++j) {
                 const double tj = taush[j];
                 double s = 0.0;
-                for (int l = ln; l < j; ++l) s += trow[l] * gsh[l][j];
+#pragma unroll
+                for (int l = 0; l < j; ++l) s += trow[l] * gsh[l][j];
                 const double tv = (ln == j) ? tj : ((ln < j) ? -tj * s : 0.0);
                 trow[j] = tv;
                 T[ln + j * PB] = tv;

@@ -308,18 +308,18 @@ __global__ __launch_bounds__(64 * NWV) void k_sb_factor_reg(SbArgs a) {
     if (a.Tsb != nullptr && w == 0) {
         double* T = a.Tsb + prob * a.sTsb;
         if (ln < 32) {
-            double* trow = L.tmat + ln * 33;
+            // row ln of T in registers, fully unrolled and branch-free (T upper triangular: trow[l] = 0 for l < ln).
+            // Gram entries exist only for pairs below s; everything else is discarded by the selects (the Gram image
+            // was also the scratch of the ranking sort).
+            double trow[32];
+#pragma unroll
             for (int b = 0; b < 32; ++b) {
-                double tv = 0.0;
-                if (b < s && ln <= b) {
-                    const double tb = L.taul[L.tslot[b]];
-                    if (ln == b) tv = tb;
-                    else {
-                        double acc = 0.0;
-                        for (int l = ln; l < b; ++l) acc += trow[l] * L.gram[l * 33 + b];
-                        tv = -tb * acc;
-                    }
-                }
+                const bool on = b < s;
+                const double tb = on ? L.taul[L.tslot[on ? b : 0]] : 0.0;
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l < b; ++l) acc += trow[l] * L.gram[l * 33 + b];
+                const double tv = on ? ((ln == b) ? tb : ((ln < b) ? -tb * acc : 0.0)) : 0.0;
                 trow[b] = tv;
                 T[ln + b * 32] = tv;
             }
