@@ -8,7 +8,7 @@ Workload (config.workload): BASELINE configs[1] "C2" — dense synthetic CNLS su
 m=4096 residuals, n=512 parameters, t=64 active (equality) constraints, fp64.  One *step* is one
 pass of the hot path (src/enlsip_functions.jl:700, 768-771, 206-234, 116-153 of the reference)
 over one batch of `--batch` independent subproblems that are already resident in HBM; the batch
-(default 256 problems = 4.3 GB of Jacobians) is larger than the 256 MB Infinity Cache so the
+(default 384 problems = 6.4 GB of Jacobians) is larger than the 256 MB Infinity Cache so the
 traffic is real HBM traffic.  value = problems solved by all ranks / wall time of the K timed
 steps (barrier + synchronize on both sides, MAX over ranks).  Ranks shard independent
 subproblems: no collective on the data path (weak scaling).
@@ -41,7 +41,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="independent C2 subproblems per GPU per step")
+    ap.add_argument("--batch", type=int, default=384, help="independent C2 subproblems per GPU per step")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the batch over this many handles/HIP streams driven by host threads")
     ap.add_argument("--m", type=int, default=4096)
@@ -171,13 +171,13 @@ def main() -> int:
             # HBM bytes per launch from the committed PMC passes of this same command and workload
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/): PMC counters
             # cannot be collected from inside the run, so the figure is carried only for a matching config.
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1c_update_traffic_pmc.json")
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1d_update_traffic_pmc.json")
             if os.path.exists(pmc):
                 with open(pmc) as fh:
                     rec = json.load(fh)
                 if rec.get("config") == {"m": m, "n": n, "t": t, "batch": B}:
                     roofline["traffic"] = rec["hbm_bytes_per_launch_avg"]
-                    roofline["traffic_source"] = "profiles/r1c_update_traffic_pmc.json"
+                    roofline["traffic_source"] = "profiles/r1d_update_traffic_pmc.json"
 
     cpu = None
     if rank == 0 and args.cpu_budget > 0:
