@@ -34,6 +34,7 @@ sys.path.insert(0, str(ROOT / "enlsip.jl_amd" / "python"))
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MEASURED_COPY_GBS = 5200.0   # in-place read+write stream, update-kernel grid (tests/microbench/access_patterns.hip)
 
 
 def main() -> int:
@@ -167,7 +168,11 @@ def main() -> int:
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 5),
-                        "algorithmic_bytes_per_launch": per_launch_bytes}
+                        "algorithmic_bytes_per_launch": per_launch_bytes,
+                        # measured ceiling of an in-place read+write stream with this kernel's grid on this chip
+                        # (tests/microbench/access_patterns.hip, profiles/r1_notes.md); `frac` stays against `peak`
+                        "measured_copy_peak": MEASURED_COPY_GBS,
+                        "frac_of_measured_copy": round(achieved / MEASURED_COPY_GBS, 4)}
             # HBM bytes per launch from the committed PMC passes of this same command and workload
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/): PMC counters
             # cannot be collected from inside the run, so the figure is carried only for a matching config.

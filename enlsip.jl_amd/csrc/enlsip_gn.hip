@@ -18,6 +18,7 @@
 #include "gn_kernels_q1_v2.hpp"
 #include "gn_kernels_update_v4.hpp"
 #include "gn_kernels_misc.hpp"
+#include "gn_kernels_lagrange.hpp"
 #include "gn_kernels_qrcp_dist.hpp"
 #include "gn_kernels_qrcp_persist.hpp"
 #include "gn_kernels_qrcp_block.hpp"
@@ -645,6 +646,8 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->ws.p) (void)hipFree(h->ws.p);
     if (h->in_stage.p) (void)hipFree(h->in_stage.p);
     if (h->out_stage.p) (void)hipFree(h->out_stage.p);
+    if (h->lag.p) (void)hipFree(h->lag.p);
+    if (h->scratch.p) (void)hipFree(h->scratch.p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_sbinfo) (void)hipHostFree(h->h_sbinfo);
     if (h->ev_ready)
@@ -823,3 +826,4 @@ int enlsip_gn_solve(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const d
 
 #include "gn_accessors.inc"
 #include "gn_tsqr.inc"
+#include "gn_lagrange.inc"

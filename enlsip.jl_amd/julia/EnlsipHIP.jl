@@ -182,4 +182,45 @@ function sub_search_direction_hip(h::Handle, m::Integer, n::Integer, t::Integer,
     return p, b, d
 end
 
+"""
+    first_lagrange_mult_estimate_hip!(h, λ, ∇fx, scaling_done, diag_scale, iter, ε_rank)
+
+Device form of `first_lagrange_mult_estimate!` (src/enlsip_functions.jl:461-508) on the resident `F_A` and `cx`
+of the last solve on `h`; writes `λ` and `iter.grad_res`.  Pass `∇fx = nothing` to use `Jᵀ rx` of the resident
+`J`, `rx` (then `gradient_hip(h, n)` returns the same vector for the caller).
+"""
+function first_lagrange_mult_estimate_hip!(h::Handle, λ::Vector{Float64}, ∇fx::Union{Nothing,Vector{Float64}},
+                                           scaling_done::Bool, diag_scale::Vector{Float64}, iter, ε_rank::Float64)
+    gres = Ref{Float64}(0.0)
+    g = ∇fx === nothing ? Ptr{Float64}(C_NULL) : pointer(∇fx)
+    ds = scaling_done ? pointer(diag_scale) : Ptr{Float64}(C_NULL)
+    GC.@preserve λ ∇fx diag_scale check(h, ccall((:enlsip_gn_first_lagrange, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ref{Float64}),
+        h.ptr, 0, g, ds, ε_rank, λ, gres))
+    iter.grad_res = gres[]
+    return
+end
+
+"""
+    second_lagrange_mult_estimate_hip!(h, λ, p_gn, scaling, diag_scale, ε_rank=sqrt(eps()))
+
+Device form of `second_lagrange_mult_estimate!` (:514-537): uses the resident `J1 = (J*F_A.Q)[:, 1:t]` instead of
+recomputing `J*F_A.Q` (:526).
+"""
+function second_lagrange_mult_estimate_hip!(h::Handle, λ::Vector{Float64}, p_gn::Vector{Float64}, scaling::Bool,
+                                            diag_scale::Vector{Float64}, ε_rank::Float64=sqrt(eps(Float64)))
+    ds = scaling ? pointer(diag_scale) : Ptr{Float64}(C_NULL)
+    GC.@preserve λ p_gn diag_scale check(h, ccall((:enlsip_gn_second_lagrange, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
+        h.ptr, 0, p_gn, ds, ε_rank, λ))
+    return
+end
+
+"""    gradient_hip(h, n) -> Jᵀ rx of the J, rx of the last solve (src/enlsip_functions.jl:2690)"""
+function gradient_hip(h::Handle, n::Integer)
+    g = zeros(Float64, n)
+    GC.@preserve g check(h, ccall((:enlsip_gn_gradient, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), h.ptr, 0, g))
+    return g
+end
+
 end # module

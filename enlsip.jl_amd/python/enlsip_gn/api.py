@@ -189,6 +189,32 @@ class GNSolver:
         self._chk(self._lib.enlsip_gn_resolve(self._h, prob, dimA, dimJ2, code, _fptr(p), _fptr(b), _fptr(d)))
         return p, b, d
 
+    # ---- multiplier estimates on the resident data (src/enlsip_functions.jl:461-537, :2690) -----------
+    def gradient(self, n: int, prob: int = 0) -> np.ndarray:
+        g = np.zeros(n)
+        self._chk(self._lib.enlsip_gn_gradient(self._h, prob, _fptr(g)))
+        return g
+
+    def first_lagrange(self, t: int, grad_fx: Optional[np.ndarray] = None, diag_scale: Optional[np.ndarray] = None,
+                       eps_rank: float = SQRT_EPS, prob: int = 0):
+        """first_lagrange_mult_estimate!: returns (lambda, grad_res)."""
+        lam = np.zeros(t)
+        gres = C.c_double(0.0)
+        g = None if grad_fx is None else np.ascontiguousarray(grad_fx, dtype=np.float64)
+        ds = None if diag_scale is None else np.ascontiguousarray(diag_scale, dtype=np.float64)
+        self._chk(self._lib.enlsip_gn_first_lagrange(self._h, prob, _fptr(g), _fptr(ds), eps_rank, _fptr(lam),
+                                                     C.byref(gres)))
+        return lam, float(gres.value)
+
+    def second_lagrange(self, t: int, p_gn: np.ndarray, diag_scale: Optional[np.ndarray] = None,
+                        eps_rank: float = SQRT_EPS, prob: int = 0) -> np.ndarray:
+        """second_lagrange_mult_estimate!: lambda from the resident J1 = (J*F_A.Q)[:, 1:t]."""
+        lam = np.zeros(t)
+        p = np.ascontiguousarray(p_gn, dtype=np.float64)
+        ds = None if diag_scale is None else np.ascontiguousarray(diag_scale, dtype=np.float64)
+        self._chk(self._lib.enlsip_gn_second_lagrange(self._h, prob, _fptr(p), _fptr(ds), eps_rank, _fptr(lam)))
+        return lam
+
     # ---- instrumentation ------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self._chk(self._lib.enlsip_gn_set_profiling(self._h, 1 if on else 0))

@@ -3,10 +3,11 @@ HIP library: same arguments, same mutations of ``W`` / ``C`` / ``iter_k``, same 
 ``(F_A, F_L11, F_J2)`` — with every ``qr(·, ColumnNorm())`` + ``gn_search_direction`` group replaced
 by ONE device solve and the factor objects replaced by device-backed views (``FactorView``).
 
-The multiplier estimates and the deletion test are the reference's host-side consumers of the
-factors; they are restated here on the accessors (``.R``, ``.p``,
-``Qt_mul``) exactly as the Julia glue would do it, so the sequencing of 1-3 subproblem solves per
-call (including quirk Q1: a first-order deletion is always undone, App. C) is reproduced.
+The multiplier estimates run on the device, on the resident ``F_A``, ``J`` and
+``J*F_A.Q`` (``GNSolver.first_lagrange`` / ``second_lagrange``); the host restatements over the accessors
+(``.R``, ``.p``, ``Qt_mul``) are kept below as the form the Julia glue would use without those entry points.
+The deletion test and the sequencing of 1-3 subproblem solves per call (including quirk Q1: a first-order
+deletion is always undone, App. C) are reproduced on the host.
 """
 from __future__ import annotations
 
@@ -182,8 +183,8 @@ def update_working_set(solver: GNSolver, W: WorkingSet, rx, A, C: Constraint, gr
 
     def _second_order(rankA, lam):
         if not (W.t != rankA or it.rankJ2 != min(m, n - rankA)):       # :745 / :773
-            F_A = solver.factor(FACTOR_A)
-            lam[:] = second_lagrange_mult_estimate(solver, J, F_A, rx, p_gn, W.t, C.scaling, C.diag_scale)
+            # second_lagrange_mult_estimate! on the device: J1 = (J*F_A.Q)[:, 1:t] is resident (:526, quirk Q6)
+            lam[:] = solver.second_lagrange(W.t, p_gn, C.diag_scale if C.scaling else None)
             s2 = check_constraint_deletion(W.q, C.A, lam, C.scaling, C.diag_scale, 0.0)
             if s2 != 0:
                 index_s2 = int(W.active[s2 - 1])
@@ -200,8 +201,8 @@ def update_working_set(solver: GNSolver, W: WorkingSet, rx, A, C: Constraint, gr
     # The reference factors A' first (:700) and only then decides; on the device the factorisation
     # comes with the full solve, which is exactly the solve of the s == 0 branch (:768-771).
     rankA = _direction()
-    F_A = solver.factor(FACTOR_A)
-    lam = first_lagrange_mult_estimate(C.A, grad_fx, C.cx, C.scaling, C.diag_scale, F_A, it, eps_rank)
+    # first_lagrange_mult_estimate! on the device, from the resident F_A and cx of the solve just done
+    lam, it.grad_res = solver.first_lagrange(W.t, grad_fx, C.diag_scale if C.scaling else None, eps_rank)
     s = check_constraint_deletion(W.q, C.A, lam, C.scaling, C.diag_scale, it.grad_res)
     if s != 0:                                                         # :706-765
         cx_s = C.cx[s - 1]

@@ -148,6 +148,25 @@ int enlsip_gn_get_JQ1(enlsip_gn_handle h, int64_t prob, double* out, int64_t ld)
 int enlsip_gn_resolve(enlsip_gn_handle h, int64_t prob, int64_t dimA, int64_t dimJ2, int64_t code,
                       double* p, double* b, double* d);
 
+/* ---- multiplier estimates on the resident data of the last solve -------------------------
+ * The two consumers the reference runs right after the subproblem, computed where F_A, J and J*F_A.Q already
+ * are instead of on copies: host vectors in / out, `prob` = problem index of the last (batched) solve,
+ * diag_scale = Constraint.diag_scale when row scaling is on (NULL: no back-transform), eps_rank as in the solve.
+ *
+ * enlsip_gn_gradient          grad = J' * rx                           src/enlsip_functions.jl:2690, :2734, :2830
+ * enlsip_gn_first_lagrange    first_lagrange_mult_estimate!            src/enlsip_functions.jl:461-508
+ *                             lambda (t) and iter.grad_res; grad_fx = NULL uses J' * rx of the resident J, rx
+ * enlsip_gn_second_lagrange   second_lagrange_mult_estimate!           src/enlsip_functions.jl:514-537
+ *                             b = J1' (rx + J p_gn) with the resident J1 = (J*F_A.Q)[:, 1:t] (the reference
+ *                             recomputes J*F_A.Q here, :526).  Returns -7 if the pseudo-rank under eps_rank
+ *                             exceeds the rank the solve used (those J1 columns were factored in place).
+ */
+int enlsip_gn_gradient(enlsip_gn_handle h, int64_t prob, double* grad);
+int enlsip_gn_first_lagrange(enlsip_gn_handle h, int64_t prob, const double* grad_fx, const double* diag_scale,
+                             double eps_rank, double* lambda, double* grad_res);
+int enlsip_gn_second_lagrange(enlsip_gn_handle h, int64_t prob, const double* p_gn, const double* diag_scale,
+                              double eps_rank, double* lambda);
+
 /* ---- row-sharded TSQR building blocks (multi-GPU config C4) ----------
  * One tall residual Jacobian whose ROWS are sharded over G GPUs; the (small) constraint data
  * At, cx are replicated.  Same mathematics as enlsip_gn_solve:  F_A, rankA, F_L11, p1 are

@@ -221,6 +221,31 @@ def test_pipelined_device_batch_matches_oracle(solver):
         assert np.allclose(np.abs(F.diagR()), np.abs(np.diag(refs[k].F_J2.R)[: len(F.diagR())]), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("kind,m,n,t,scaling", [("full", 600, 40, 6, False), ("full", 4096, 512, 64, True),
+                                                 ("rankdefA", 300, 40, 6, False), ("full", 200, 30, 30, True)])
+def test_multiplier_estimates_on_device(kind, m, n, t, scaling, solver):
+    """enlsip_gn_gradient / _first_lagrange / _second_lagrange against the oracle's restatement of
+    first/second_lagrange_mult_estimate! (src/enlsip_functions.jl:461-537) on the same problem."""
+    gen = synth.make_rank_deficient_A if kind == "rankdefA" else synth.make_problem
+    J, rx, A, cx = gen(4242 + m + n, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    out = solver.solve(J, rx, A, cx)
+    assert out.rankA == ref.rankA
+    diag_scale = 1.0 + 0.25 * np.abs(synth.normal_stream(77, 5, t)) if scaling else np.ones(t)
+    grad = J.T @ rx
+    g_dev = solver.gradient(n)
+    assert rel(g_dev, grad) <= 1e-13
+    it = go.IterationRecord()
+    lam_ref = go.first_lagrange_mult_estimate(A, grad, cx, scaling, diag_scale, ref.F_A, it, go.SQRT_EPS)
+    for gfx in (grad, None):                       # host gradient and the device-computed one
+        lam, gres = solver.first_lagrange(t, gfx, diag_scale if scaling else None)
+        assert rel(lam, lam_ref) <= 1e-10
+        assert abs(gres - it.grad_res) <= 1e-10 * max(1.0, abs(it.grad_res))
+    lam2_ref = go.second_lagrange_mult_estimate(J, ref.F_A, rx, ref.p, t, scaling, diag_scale)
+    lam2 = solver.second_lagrange(t, out.p, diag_scale if scaling else None)
+    assert rel(lam2, lam2_ref) <= 1e-9
+
+
 def test_argument_errors(solver):
     from enlsip_gn import GNError
     J, rx, A, cx = synth.make_problem(1, 50, 10, 2)
