@@ -34,7 +34,7 @@ sys.path.insert(0, str(ROOT / "enlsip.jl_amd" / "python"))
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-MEASURED_COPY_GBS = 5200.0   # in-place read+write stream, update-kernel grid (tests/microbench/access_patterns.hip)
+MEASURED_COPY_GBS = 5785.0   # in-place read+write stream with non-temporal loads and stores, update-kernel grid (tests/microbench/copy_variants.hip; 5.3 TB/s with plain accesses)
 
 
 def main() -> int:

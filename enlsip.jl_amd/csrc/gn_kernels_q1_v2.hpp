@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         {
             const char* src = (const char*)(Jin + (size_t)(16 * (w + Q2_NW * T) + 4 * r) * a.ldj + row0) + jlane;
             if (NP == 2) {
-                const v4_d2 x = *(const v4_d2*)src;
+                const v4_d2 x = __builtin_nontemporal_load((const v4_d2*)src);     // J is streamed once
                 jt[T][r][0] = x[0];
                 jt[T][r][NP - 1] = x[1];
             } else {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) dp[p] += jt[T][r][p] * pc;
             char* dst = (char*)(W + (size_t)(16 * (w + Q2_NW * T) + 4 * r) * ldw + row0) + wlane;   // W 256-byte aligned
-            if (NP == 2) *(v4_d2*)dst = (v4_d2){jt[T][r][0], jt[T][r][NP - 1]};
+            if (NP == 2) __builtin_nontemporal_store((v4_d2){jt[T][r][0], jt[T][r][NP - 1]}, (v4_d2*)dst);
             else *(double*)dst = jt[T][r][0];
         }
 #pragma unroll

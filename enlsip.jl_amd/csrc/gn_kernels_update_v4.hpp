@@ -119,7 +119,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (V4_ABLATE == 3 || V4_ABLATE == 5) cp[g][ct][r] = (v4_d2){(double)(g + r), (double)ct};
-                else cp[g][ct][r] = *(const v4_d2*)cptr(g, ct, r);
+                else cp[g][ct][r] = __builtin_nontemporal_load((const v4_d2*)cptr(g, ct, r));   // streamed once: keep it out of L2's way
             }
     };
     auto finish_c = [&](int g) {
@@ -296,7 +296,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                     if (fr[0][ct][r] == 1.2345e301) c.C[0] = fr[1][ct][r];
                 } else if (CFULL || ((smask >> (4 * ct + r)) & 1u)) {
                     if (!RMASK) {
-                        *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
+                        __builtin_nontemporal_store((v4_d2){fr[0][ct][r], fr[1][ct][r]}, (v4_d2*)cptr(g, ct, r));
                     } else {
                         const int s0 = slot0(g) + 2 * lr;
                         if (s0 + 1 < c.rows_valid) *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
