@@ -21,6 +21,7 @@ struct ConstraintArgs {
     int dimA_override;   // -1 = rankA
     int code_override;   // 0 = derive from rankA; +1 / -1 force (resolve path)
     int prob0;           // problem index offset
+    int fa_done;         // 1: F_A, tau_A, jpvt_A and the block T factor were produced by k_geqp3_reg
     // inputs
     const double* At;    long long ldat, strideAt;   // n x t
     const double* cx;    long long stride_cx;        // t
@@ -69,16 +70,18 @@ __global__ __launch_bounds__(1024) void k_constraint(ConstraintArgs a) {
 
     if (tid == 0) sh_i[2] = 0;  // status accumulator
     // ---- F_A ------------------------------------------------------------------------------
-    const bool fa_lds = (size_t)n * t <= (size_t)CMAT_DOUBLES;
-    double* WA = fa_lds ? mat : FA;
-    for (int e = tid; e < n * t; e += nt) {
-        const int r = e % n, c = e / n;
-        WA[r + (size_t)c * n] = At[r + (size_t)c * a.ldat];
-    }
-    __syncthreads();
-    if (t > 0) wg_geqp2<RPL, G>(WA, n, n, t, 0, tauA, jpvtA, vn1, vn2, sh_i);
-    if (fa_lds) {
-        for (int e = tid; e < n * t; e += nt) FA[e] = mat[e];
+    if (!a.fa_done) {
+        const bool fa_lds = (size_t)n * t <= (size_t)CMAT_DOUBLES;
+        double* WA = fa_lds ? mat : FA;
+        for (int e = tid; e < n * t; e += nt) {
+            const int r = e % n, c = e / n;
+            WA[r + (size_t)c * n] = At[r + (size_t)c * a.ldat];
+        }
+        __syncthreads();
+        if (t > 0) wg_geqp2<RPL, G>(WA, n, n, t, 0, tauA, jpvtA, vn1, vn2, sh_i);
+        if (fa_lds) {
+            for (int e = tid; e < n * t; e += nt) FA[e] = mat[e];
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(1024) void k_constraint(ConstraintArgs a) {
 
     // ---- block T factors of Q1 (dlarft, forward columnwise), KBLK reflectors per block --------
     // Gram G = V'V accumulated from 32-row chunks of V staged in LDS; T recurrence in LDS.
-    const int nblk = (kA + KBLK - 1) / KBLK;
+    const int nblk = a.fa_done ? 0 : (kA + KBLK - 1) / KBLK;
     for (int blkid = 0; blkid < nblk; ++blkid) {
         const int c0 = blkid * KBLK;
         const int kb = (kA - c0) < KBLK ? (kA - c0) : KBLK;

@@ -1,0 +1,233 @@
+// Column-pivoted Householder QR (dgeqp3 pivot rule, dlaqp2 arithmetic) of ONE small matrix per workgroup with the whole
+// matrix in registers: rows <= 64 * RPL (lane = row), cols <= 64 (8 waves x 8 columns).  Used for F_A = qr(C.A',
+// ColumnNorm()) (src/enlsip_functions.jl:700) when A' does not fit the LDS area of k_constraint (C2: 512 x 64 = 256 KB),
+// where the generic workgroup routine works out of L2 and pays three dependent memory round trips per pivot step.
+// Same step structure as k_sb_factor_reg (gn_kernels_qrcp_block_reg.hpp); columns never move, positions are logical, and
+// the LAPACK layout (columns in pivot order, V below / R on and above the diagonal, tau, 1-based jpvt) is produced by the
+// write-back.  The dot products with already retired columns are the Gram entries of the dlarft T factor of the (single)
+// compact-WY block of Q1, which is written too (kA <= 64).
+#pragma once
+#include "gn_kernels_constraint.hpp"
+
+namespace gn {
+
+struct Geqp3RegArgs {
+    int rows, cols;            // A is rows x cols (n x t)
+    const double* A;  long long lda, strideA;
+    double* F;        long long sF;      // rows x cols, ld = rows (compact factors)
+    double* tau;      long long sTau;
+    long long* jpvt;  long long sJ;
+    double* T;        long long sT;      // 64 x 64 block T factor (column-major, zero padded); may be null
+    int prob0;
+};
+
+template <int RPL>
+__global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
+    constexpr int NWV = 8, NCW = 8;
+    __shared__ double vsh[2][64 * RPL];
+    __shared__ double cvn1[2][64], cvn2[64], taul[64];
+    __shared__ int cpos[2][64], colat[64], tslot[64];
+    __shared__ double gram[64 * 65];
+    __shared__ double tau_s[2];
+    const int prob = blockIdx.x + a.prob0;
+    const int rows = a.rows, cols = a.cols;
+    const int tid = threadIdx.x, ln = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const double* A = a.A + prob * a.strideA;
+    double* F = a.F + prob * a.sF;
+    const double tol3z = 1.4901161193847656e-08;
+    const int kmax = rows < cols ? rows : cols;
+
+    // columns -> registers: column c = w + 8 cc, row ln + 64 i
+    double x[NCW][RPL];
+    double nrm[NCW];
+#pragma unroll
+    for (int cc = 0; cc < NCW; ++cc) {
+        const int c = w + NWV * cc;
+        nrm[cc] = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = ln + 64 * i;
+            x[cc][i] = (c < cols && r < rows) ? A[r + (size_t)c * a.lda] : 0.0;
+            nrm[cc] += x[cc][i] * x[cc][i];
+        }
+    }
+    {
+        double ns[NCW];
+        wave_allsum8(nrm, ns);
+#pragma unroll
+        for (int cc = 0; cc < NCW; ++cc) {
+            const int c = w + NWV * cc;
+            if (ln == 0 && c < 64) {
+                const double v0 = (c < cols) ? sqrt(ns[cc]) : 0.0;
+                cvn1[0][c] = v0;
+                cvn2[c] = v0;
+                cpos[0][c] = (c < cols) ? c : -1000;      // -1000: no such column
+                colat[c] = c;
+            }
+        }
+    }
+    for (int e = tid; e < 64 * 65; e += 512) gram[e] = 0.0;
+    if (tid < 64) taul[tid] = 0.0;
+    __syncthreads();
+
+    int s = 0;
+    for (; s < kmax; ++s) {
+        int lnl = ln, wl = w;                              // opaque copies: keep LICM from hoisting the per-column masks
+        asm volatile("" : "+v"(lnl));
+        asm volatile("" : "+s"(wl));
+        const int rd = s & 1, wr = rd ^ 1;
+        // pivot: largest partial norm among the active columns, ties -> lowest current position (idamax)
+        double bv = -1.0;
+        int bp = 0x7fffffff, bk = -1;
+        if (cpos[rd][lnl] >= 0) {
+            bv = cvn1[rd][lnl];
+            bp = cpos[rd][lnl];
+            bk = lnl;
+        }
+        const ArgMax am = wave_argmax(bv, bp, bk);
+        const int ci = am.idx, q = am.pos;
+        if (wl == ci % NWV) {
+#pragma unroll
+            for (int cc = 0; cc < NCW; ++cc) {
+                if (cc == ci / NWV) {
+                    double xn2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i)
+                        if (lnl + 64 * i > s) xn2 += x[cc][i] * x[cc][i];
+                    xn2 = wave_allsum(xn2);
+                    const double alpha = wave_bcast(x[cc][0], s);      // s < 64: the pivot row sits in register 0
+                    const Reflector h = make_reflector(alpha, xn2);
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) {
+                        const int r = lnl + 64 * i;
+                        const double v = (r > s) ? x[cc][i] * h.scale : (r == s ? 1.0 : 0.0);
+                        vsh[rd][r] = v;
+                        if (r > s) x[cc][i] = v;
+                        if (r == s) x[cc][i] = h.beta;
+                    }
+                    if (lnl == 0) {
+                        taul[s] = h.tau;
+                        tau_s[rd] = h.tau;
+                        tslot[s] = ci;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        double v[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) v[i] = vsh[rd][lnl + 64 * i];
+        const double tj = tau_s[rd];
+        double dot[NCW], ds[NCW];
+#pragma unroll
+        for (int cc = 0; cc < NCW; ++cc) {
+            dot[cc] = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) dot[cc] += x[cc][i] * v[i];
+        }
+        wave_allsum8(dot, ds);
+        double ajc8[NCW];
+        unsigned actm = 0u;
+#pragma unroll
+        for (int cc = 0; cc < NCW; ++cc) {
+            const int c = wl + NWV * cc;
+            ajc8[cc] = 0.0;
+            if (c == ci) continue;
+            const int pk = cpos[rd][c];
+            if (pk >= 0) {
+                if (tj != 0.0) {
+                    const double wd = tj * ds[cc];
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) x[cc][i] -= wd * v[i];
+                }
+                ajc8[cc] = wave_bcast(x[cc][0], s);
+                actm |= 1u << cc;
+            } else if (pk > -1000) {
+                if (lnl == 0) gram[(-1 - pk) * 65 + s] = ds[cc];      // v_a' v_s, a = step that retired this column
+            }
+        }
+        {   // dlaqp2 norm downdate, lane u < 8 <-> column u of this wave
+            const int u = lnl & (NCW - 1);
+            const int cu = wl + NWV * u;
+            const bool mine = (lnl < NCW) && ((actm >> u) & 1u);
+            double ajc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NCW; ++cc) ajc = (u == cc) ? ajc8[cc] : ajc;
+            double o1 = mine ? cvn1[rd][cu] : 0.0;
+            const double o2 = mine ? cvn2[cu] : 1.0;
+            bool need = false;
+            if (mine && o1 != 0.0) {
+                double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
+                temp = temp > 0.0 ? temp : 0.0;
+                const double qq = o1 / o2;
+                const double temp2 = temp * qq * qq;
+                if (temp2 <= tol3z) need = true;
+                else o1 = o1 * sqrt(temp);
+            }
+            unsigned nm = (unsigned)(__ballot(need) & 0xffull);
+            while (nm) {
+                const int uu = __ffs((int)nm) - 1;
+                nm &= nm - 1;
+                double sq = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < NCW; ++cc)
+                    if (cc == uu) {
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i)
+                            if (lnl + 64 * i > s) sq += x[cc][i] * x[cc][i];
+                    }
+                sq = wave_allsum(sq);
+                if (lnl == uu) {
+                    o1 = (s + 1 < rows) ? sqrt(sq) : 0.0;
+                    cvn2[cu] = o1;
+                }
+            }
+            if (mine) cvn1[wr][cu] = o1;
+        }
+        // positions: the pivot (at position q) trades places with the column that sat at position s
+        if (wl == 0) {
+            const int cj = colat[s];
+            const int old = cpos[rd][lnl];
+            cpos[wr][lnl] = (lnl == ci) ? (-1 - s) : ((lnl == cj && cj != ci) ? q : old);
+            if (lnl == 0) {
+                colat[s] = ci;
+                colat[q] = cj;
+            }
+        }
+        __syncthreads();
+    }
+    const int fin = s & 1;
+    // ---- write-back in LAPACK layout: the column at final position p goes to F[:, p] -----------------------------
+#pragma unroll
+    for (int cc = 0; cc < NCW; ++cc) {
+        const int c = w + NWV * cc;
+        if (c >= cols) continue;
+        const int pk = cpos[fin][c];
+        const int p = (pk < 0) ? (-1 - pk) : pk;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = ln + 64 * i;
+            if (r < rows) F[r + (size_t)p * rows] = x[cc][i];
+        }
+        if (ln == 0) a.jpvt[prob * a.sJ + p] = c + 1;
+    }
+    if (tid < kmax) a.tau[prob * a.sTau + tid] = taul[tid];
+    // ---- T factor of the compact-WY block (dlarft forward / columnwise), unrolled in registers -------------------
+    if (a.T != nullptr && w == 0) {
+        double* T = a.T + prob * a.sT;
+        double trow[64];
+#pragma unroll
+        for (int b = 0; b < 64; ++b) {
+            const double tb = (b < s) ? taul[b] : 0.0;
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < b; ++l) acc += trow[l] * gram[l * 65 + b];
+            const double tv = (ln == b) ? tb : ((ln < b) ? -tb * acc : 0.0);
+            trow[b] = tv;
+            T[ln + b * KBLK] = tv;
+        }
+    }
+}
+
+}  // namespace gn
