@@ -65,24 +65,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
     const int bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
     const int col0 = st.rankA + r0;
     const int g = blockIdx.x;
-    const int ln = lane_id(), w = wave_id();
+    const int ln = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
     double* W = a.W + prob * a.sW;
     const bool tri = a.level > 0;
 
     for (int e = threadIdx.x; e < PB * (PB + 1); e += NT) (&gsh[0][0])[e] = 0.0;
     if (threadIdx.x < PB) taush[threadIdx.x] = 0.0;
 
-    // slot geometry of this lane
+    // slot geometry of this lane: slot ln + 64 i = block q = (ln >> 5) + 2 i of the group, row rb of that block.
+    // Address = wave-uniform part (column, block pair i) + ONE per-lane offset: no per-slot address registers.
     const int rb = ln & 31;
-    long long rowoff[RPL];
-    bool bval[RPL];
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-        const int q = (ln >> 5) + 2 * i;
-        const long long bidx = (long long)g * a.F + q;
-        bval[i] = bidx < a.nblocks;
-        rowoff[i] = r0 + bidx * a.S + rb;
-    }
+    const int qh = ln >> 5;
+    const long long lane_off = (long long)qh * a.S + rb;
+    auto ubase = [&](int c, int i) -> size_t {        // uniform
+        return (size_t)(col0 + c) * a.ldw + (size_t)(r0 + ((long long)g * a.F + 2 * i) * a.S);
+    };
+    auto bval = [&](int i) -> bool { return (long long)g * a.F + qh + 2 * i < a.nblocks; };
     // load the tile: a[cc][i] = element (slot ln + 64 i, column w + NW cc)
     double x[NC][RPL];
 #pragma unroll
@@ -90,8 +89,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
         const int c = w + NW * cc;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const bool ok = (c < bw) && bval[i] && (!tri || rb <= c);
-            x[cc][i] = ok ? W[rowoff[i] + (size_t)(col0 + c) * a.ldw] : 0.0;
+            const bool ok = (c < bw) && bval(i) && (!tri || rb <= c);
+            x[cc][i] = ok ? W[ubase(c, i) + lane_off] : 0.0;
         }
     }
     __syncthreads();
@@ -99,6 +98,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
 #pragma unroll
     for (int jj = 0; jj < NC; ++jj) {
         for (int jw = 0; jw < NW; ++jw) {
+            int lnl = ln;                      // opaque per-iteration copy: keeps LICM from hoisting (and spilling) the row masks
+            asm volatile("" : "+v"(lnl));
             const int j = NW * jj + jw;  // wave-uniform
             if (j < bw) {
                 const int buf = j & 1;
@@ -107,24 +108,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
                     double xn2 = 0.0;
 #pragma unroll
                     for (int i = 0; i < RPL; ++i)
-                        if (ln + 64 * i > j) xn2 += x[jj][i] * x[jj][i];
+                        if (lnl + 64 * i > j) xn2 += x[jj][i] * x[jj][i];
                     xn2 = wave_allsum(xn2);
                     const double alpha = wave_bcast(x[jj][0], j);
                     const Reflector h = make_reflector(alpha, xn2);
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) {
-                        const int s = ln + 64 * i;
+                        const int s = lnl + 64 * i;
                         const double v = (s > j) ? x[jj][i] * h.scale : (s == j ? 1.0 : 0.0);
                         vsh[buf][s] = v;
                         if (s > j) x[jj][i] = v;
                         if (s == j) x[jj][i] = h.beta;
                     }
-                    if (ln == 0) taush[j] = h.tau;
+                    if (lnl == 0) taush[j] = h.tau;
                 }
                 __syncthreads();
                 double v[RPL];
 #pragma unroll
-                for (int i = 0; i < RPL; ++i) v[i] = vsh[buf][ln + 64 * i];
+                for (int i = 0; i < RPL; ++i) v[i] = vsh[buf][lnl + 64 * i];
                 const double tj = taush[j];
                 double dot[NC];
 #pragma unroll
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
                     } else if (c < j) {
                         // Gram entry v_c' v_j for the T factor: rows above slot j are masked by
                         // v (zero there), so the R entries held in x[cc] do not contribute
-                        if (ln == 0) gsh[c][j] = ds[cc];
+                        if (lnl == 0) gsh[c][j] = ds[cc];
                     }
                 }
             }
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
         const int c = w + NW * cc;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const bool ok = (c < bw) && bval[i] && (!tri || rb <= c);
-            if (ok) W[rowoff[i] + (size_t)(col0 + c) * a.ldw] = x[cc][i];
+            const bool ok = (c < bw) && bval(i) && (!tri || rb <= c);
+            if (ok) W[ubase(c, i) + lane_off] = x[cc][i];
         }
     }
     // T factor (dlarft forward/columnwise): lane r of wave 0 builds row r
