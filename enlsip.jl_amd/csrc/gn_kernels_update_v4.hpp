@@ -250,7 +250,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             t = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, b, t, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) W2l[(16 * it2 + lq + 4 * r) * PB + 16 * ct2 + lr] = -t[r];
+        for (int r = 0; r < 4; ++r) W2l[(16 * it2 + lq + 4 * r) * PB + ((16 * ct2 + lr) ^ (16 * (lq & 1)))] = -t[r];   // swizzled, see the read
     }
     __syncthreads();
 
@@ -276,7 +276,9 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             for (int ct = 0; ct < NCT; ++ct) {
                 double a2[4];
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) a2[k4] = W2l[(16 * h + 4 * k4 + lq) * PB + 16 * ct + lr];   // A[i = col][k]
+                // A[i = col][k]; rows k and k + 1 (the two 16-lane groups of a half-wave) are 256 B apart = same banks, so odd
+                // rows are stored with their two column halves exchanged: conflict-free ds_read_b64
+                for (int k4 = 0; k4 < 4; ++k4) a2[k4] = W2l[(16 * h + 4 * k4 + lq) * PB + ((16 * ct + lr) ^ (16 * (lq & 1)))];
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
