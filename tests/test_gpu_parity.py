@@ -221,6 +221,43 @@ def test_pipelined_device_batch_matches_oracle(solver):
         assert np.allclose(np.abs(F.diagR()), np.abs(np.diag(refs[k].F_J2.R)[: len(F.diagR())]), rtol=1e-9, atol=1e-12)
 
 
+def test_pipelined_batch_on_caller_stream():
+    """Inputs produced on the caller's stream right before the call: the second pipeline half runs on the library's own
+    stream and must be ordered after them (event fork in enlsip_gn_solve_batched_dev)."""
+    import torch
+    from enlsip_gn import GNSolver
+    batch, m, n, t = 140, 128, 16, 3
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    Js, rxs, Ats, cxs, refs = [], [], [], [], []
+    for k in range(batch):
+        J, rx, A, cx = synth.make_problem(12000 + k, m, n, t)
+        Js.append(np.ascontiguousarray(J.T)); rxs.append(rx); Ats.append(np.ascontiguousarray(A)); cxs.append(cx)
+        refs.append(go.gn_subproblem(J, rx, A, cx))
+    hJ = torch.from_numpy(np.stack(Js)).pin_memory()
+    hrx = torch.from_numpy(np.stack(rxs)).pin_memory()
+    hAt = torch.from_numpy(np.stack(Ats)).pin_memory()
+    hcx = torch.from_numpy(np.stack(cxs)).pin_memory()
+    s = GNSolver(device=0, stream=st.cuda_stream)
+    try:
+        with torch.cuda.stream(st):
+            big = torch.randn(64, 1024, 1024, device=dev)          # keeps the stream busy for a while
+            big = (big @ big).sum()
+            dJ = hJ.to(dev, non_blocking=True) * 1.0               # inputs become valid only when the stream gets here
+            drx = hrx.to(dev, non_blocking=True) * 1.0
+            dAt = hAt.to(dev, non_blocking=True) * 1.0
+            dcx = hcx.to(dev, non_blocking=True) * 1.0
+            dp = torch.zeros(batch, n, dtype=torch.float64, device=dev)
+            s.solve_batched_dev(batch, m, n, t, dJ.data_ptr(), m, m * n, drx.data_ptr(), dAt.data_ptr(), n, n * t,
+                                dcx.data_ptr(), dp=dp.data_ptr())
+        st.synchronize()
+        p = dp.cpu().numpy()
+        for k, ref in enumerate(refs):
+            assert rel(p[k], ref.p) <= TOL_P, k
+    finally:
+        s.close()
+
+
 @pytest.mark.parametrize("kind,m,n,t,scaling", [("full", 600, 40, 6, False), ("full", 4096, 512, 64, True),
                                                  ("rankdefA", 300, 40, 6, False), ("full", 200, 30, 30, True)])
 def test_multiplier_estimates_on_device(kind, m, n, t, scaling, solver):
