@@ -221,6 +221,33 @@ def test_pipelined_device_batch_matches_oracle(solver):
         assert np.allclose(np.abs(F.diagR()), np.abs(np.diag(refs[k].F_J2.R)[: len(F.diagR())]), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("kind,m,n,t", [
+    ("full", 600, 300, 40),          # F_A in registers (n t > 8192, RPL 8), blocked pivoted QR with RPL 8
+    ("full", 1000, 512, 20),         # register F_A with few columns, n2 = 492
+    ("full", 700, 257, 33),          # odd sizes, register F_A (RPL 8), kp = 224
+    ("full", 900, 400, 64),          # t = 64 = the widest register F_A
+    ("full", 350, 200, 50),          # register F_A with RPL 4, blocked QR with RPL 4
+    ("rankdefA", 800, 300, 40),      # code -1 through the register F_A
+    ("rankdefJ", 900, 260, 35),      # rank-deficient J2 through the blocked pivoted QR
+    ("graded", 1200, 280, 30),       # graded singular values: norm-downdate recomputations
+    ("full", 300, 330, 40),          # m < n2: kp = m
+    ("full", 513, 140, 0),           # no constraints, one row past a tile boundary
+])
+def test_shape_sweep_register_paths(kind, m, n, t, solver):
+    """Shapes chosen to run the register-resident factorisations (k_geqp3_reg, k_sb_factor_reg), the gathered block
+    update and the one-tile / partial-unit variants of the trailing update away from the C2 benchmark shape."""
+    gen = {"full": synth.make_problem, "rankdefA": synth.make_rank_deficient_A, "rankdefJ": synth.make_rank_deficient_J,
+           "graded": synth.make_graded_J}[kind]
+    J, rx, A, cx = gen(31000 + m + n + t, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    out = solver.solve(J, rx, A, cx)
+    if kind in ("full",):
+        compare(out, ref, m, n)
+    else:
+        assert out.rankA == ref.rankA and out.rankJ2 == ref.rankJ2 and out.code == ref.code
+        assert rel(out.p, ref.p) <= (1e-6 if kind == "graded" else 1e-9)
+
+
 def test_pipelined_batch_on_caller_stream():
     """Inputs produced on the caller's stream right before the call: the second pipeline half runs on the library's own
     stream and must be ordered after them (event fork in enlsip_gn_solve_batched_dev)."""
