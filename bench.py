@@ -176,13 +176,13 @@ def main() -> int:
             # HBM bytes per launch from the committed PMC passes of this same command and workload
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/): PMC counters
             # cannot be collected from inside the run, so the figure is carried only for a matching config.
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1d_update_traffic_pmc.json")
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1e_update_traffic_pmc.json")
             if os.path.exists(pmc):
                 with open(pmc) as fh:
                     rec = json.load(fh)
                 if rec.get("config") == {"m": m, "n": n, "t": t, "batch": B}:
                     roofline["traffic"] = rec["hbm_bytes_per_launch_avg"]
-                    roofline["traffic_source"] = "profiles/r1d_update_traffic_pmc.json"
+                    roofline["traffic_source"] = "profiles/r1e_update_traffic_pmc.json"
 
     cpu = None
     if rank == 0 and args.cpu_budget > 0:
