@@ -84,8 +84,10 @@ __global__ __launch_bounds__(1024) void k_constraint(ConstraintArgs a) {
         }
     }
     __syncthreads();
+    for (int i = tid; i < kA; i += nt) ybuf[i] = FA[i + (size_t)i * n];      // diagonal -> LDS in parallel (see k_pivot_solve)
+    __syncthreads();
     if (tid == 0) {
-        int rk = pseudo_rank_serial(kA, a.eps_rank, [&](int i) { return FA[i + (size_t)i * n]; });
+        int rk = pseudo_rank_serial(kA, a.eps_rank, [&](int i) { return ybuf[i]; });
         sh_i[1] = rk;
     }
     __syncthreads();

@@ -93,16 +93,14 @@ __global__ __launch_bounds__(1024) void k_pivot_solve(FinalArgs a) {
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            sh_i[1] = pseudo_rank_serial(kp, a.eps_rank, [&](int i) { return Rt[i + (size_t)i * ldr]; });
-        }
-        __syncthreads();
-        rankJ2 = sh_i[1];
-    } else if (a.refactor == 2) {
-        // factors were produced by the distributed pivoted QR (gn_kernels_qrcp_dist.hpp)
+    }
+    if (a.refactor == 1 || a.refactor == 2) {
+        // (refactor == 2: the factors were produced by the blocked / distributed pivoted QR.)  The diagonal goes to LDS
+        // in parallel first: one thread walking it in global memory pays an L2 round trip per entry (0.3 ms at kp = 448).
+        for (int i = tid; i < kp; i += nt) pbuf[i] = Rt[i + (size_t)i * ldr];
         __syncthreads();
         if (tid == 0) {
-            sh_i[1] = pseudo_rank_serial(kp, a.eps_rank, [&](int i) { return Rt[i + (size_t)i * ldr]; });
+            sh_i[1] = pseudo_rank_serial(kp, a.eps_rank, [&](int i) { return pbuf[i]; });
         }
         __syncthreads();
         rankJ2 = sh_i[1];

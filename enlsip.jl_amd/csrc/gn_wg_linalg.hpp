@@ -220,12 +220,14 @@ __device__ void wg_trsv(const double* __restrict__ T, int ld, int dim, double* y
         if (LOWER) {
             for (int r = i0 + nb + threadIdx.x; r < dim; r += blockDim.x) {
                 double s = 0.0;
-                for (int c = 0; c < nb; ++c) s += T[r + (size_t)(i0 + c) * ld] * y[i0 + c];
+#pragma unroll 8
+                for (int c = 0; c < nb; ++c) s += T[r + (size_t)(i0 + c) * ld] * y[i0 + c];   // 8 independent loads in flight
                 y[r] -= s;
             }
         } else {
             for (int r = threadIdx.x; r < i0; r += blockDim.x) {
                 double s = 0.0;
+#pragma unroll 8
                 for (int c = 0; c < nb; ++c) s += T[r + (size_t)(i0 + c) * ld] * y[i0 + c];
                 y[r] -= s;
             }
