@@ -17,6 +17,7 @@
 #include "gn_kernels_q1.hpp"
 #include "gn_kernels_q1_mfma.hpp"
 #include "gn_kernels_q1_v2.hpp"
+#include "gn_kernels_q1_rows.hpp"
 #include "gn_kernels_update_v4.hpp"
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_lagrange.hpp"
@@ -178,21 +179,27 @@ static void big_lds(KernelT k, size_t bytes) {
     } while (0)
 
 // dispatch helpers over the rows-per-lane instantiations of the single-workgroup kernels
-static void launch_constraint(int rows, int batch, hipStream_t s, const ConstraintArgs& a) {
-    const size_t lds = (size_t)CONSTRAINT_LDS_DOUBLES * 8;
-    if (rows <= 64) GN_LAUNCH_BIG((k_constraint<1, 8>), dim3(batch), dim3(1024), lds, s, a);
-    else if (rows <= 128) GN_LAUNCH_BIG((k_constraint<2, 8>), dim3(batch), dim3(1024), lds, s, a);
-    else if (rows <= 256) GN_LAUNCH_BIG((k_constraint<4, 8>), dim3(batch), dim3(1024), lds, s, a);
-    else if (rows <= 512) GN_LAUNCH_BIG((k_constraint<8, 4>), dim3(batch), dim3(1024), lds, s, a);
-    else GN_LAUNCH_BIG((k_constraint<16, 2>), dim3(batch), dim3(1024), lds, s, a);
+// Problems with at most 64 rows run with 256 or 512 threads and an LDS carve sized to the problem, so that batches of
+// small problems (C3, C5) keep several workgroups resident per CU; larger ones use 1024 threads.
+static void launch_constraint(int rows, int batch, hipStream_t s, ConstraintArgs a) {
+    constraint_carve(a.n, a.t, a.fa_done, a.nv, a.blkd, a.gld, a.matd);
+    const size_t lds = constraint_lds_bytes(a.nv, a.blkd, a.gld, a.matd);
+    if (rows <= 32) GN_LAUNCH_BIG((k_constraint<1, 8, 256>), dim3(batch), dim3(256), lds, s, a);
+    else if (rows <= 64) GN_LAUNCH_BIG((k_constraint<1, 8, 512>), dim3(batch), dim3(512), lds, s, a);
+    else if (rows <= 128) GN_LAUNCH_BIG((k_constraint<2, 8, 1024>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 256) GN_LAUNCH_BIG((k_constraint<4, 8, 1024>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 512) GN_LAUNCH_BIG((k_constraint<8, 4, 1024>), dim3(batch), dim3(1024), lds, s, a);
+    else GN_LAUNCH_BIG((k_constraint<16, 2, 1024>), dim3(batch), dim3(1024), lds, s, a);
 }
-static void launch_pivot(int rows, int batch, hipStream_t s, const FinalArgs& a) {
-    const size_t lds = (size_t)FINAL_LDS_DOUBLES * 8;
-    if (rows <= 64) GN_LAUNCH_BIG((k_pivot_solve<1, 8>), dim3(batch), dim3(1024), lds, s, a);
-    else if (rows <= 128) GN_LAUNCH_BIG((k_pivot_solve<2, 8>), dim3(batch), dim3(1024), lds, s, a);
-    else if (rows <= 256) GN_LAUNCH_BIG((k_pivot_solve<4, 8>), dim3(batch), dim3(1024), lds, s, a);
-    else if (rows <= 512) GN_LAUNCH_BIG((k_pivot_solve<8, 4>), dim3(batch), dim3(1024), lds, s, a);
-    else GN_LAUNCH_BIG((k_pivot_solve<16, 2>), dim3(batch), dim3(1024), lds, s, a);
+static void launch_pivot(int rows, int batch, hipStream_t s, FinalArgs a) {
+    final_carve(a.m, a.n, a.t, a.nv, a.matd);
+    const size_t lds = final_lds_bytes(a.nv, a.matd);
+    if (rows <= 32) GN_LAUNCH_BIG((k_pivot_solve<1, 8, 256>), dim3(batch), dim3(256), lds, s, a);
+    else if (rows <= 64) GN_LAUNCH_BIG((k_pivot_solve<1, 8, 512>), dim3(batch), dim3(512), lds, s, a);
+    else if (rows <= 128) GN_LAUNCH_BIG((k_pivot_solve<2, 8, 1024>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 256) GN_LAUNCH_BIG((k_pivot_solve<4, 8, 1024>), dim3(batch), dim3(1024), lds, s, a);
+    else if (rows <= 512) GN_LAUNCH_BIG((k_pivot_solve<8, 4, 1024>), dim3(batch), dim3(1024), lds, s, a);
+    else GN_LAUNCH_BIG((k_pivot_solve<16, 2, 1024>), dim3(batch), dim3(1024), lds, s, a);
 }
 
 static CaqrArgs caqr_args(enlsip_gn_handle h, int k, const LevelPlan& L) {
@@ -493,6 +500,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         qa.W = h->W; qa.sW = P.sW; qa.state = h->state;
         qa.prob0 = 0;
         if (h->flags & ENLSIP_GN_UPDATE_REFLECTORS) launch_jq1(qa, (int)batch, s);   // plain-FMA A/B partner
+        else if (launch_jq1_rows(qa, (int)batch, s)) {}                             // small n, few reflectors
         else if (getenv("ENLSIP_GN_JQ1_V1") || !launch_jq1_v2(qa, (int)batch, s)) launch_jq1_mfma(qa, (int)batch, s);
         mark(2);
         // 3. CAQR of [J2 | d]

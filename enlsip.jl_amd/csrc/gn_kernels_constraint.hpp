@@ -22,6 +22,7 @@ struct ConstraintArgs {
     int code_override;   // 0 = derive from rankA; +1 / -1 force (resolve path)
     int prob0;           // problem index offset
     int fa_done;         // 1: F_A, tau_A, jpvt_A and the block T factor were produced by k_geqp3_reg
+    int nv, blkd, gld, matd;   // LDS carve in doubles (constraint_carve)
     // inputs
     const double* At;    long long ldat, strideAt;   // n x t
     const double* cx;    long long stride_cx;        // t
@@ -38,19 +39,31 @@ struct ConstraintArgs {
     ProbState* state;
 };
 
-// LDS carve (doubles): vn1[1024] vn2[1024] blk[64*65] gl[64*64] ybuf[1024] mat[8192] + 16 ints
-constexpr int CONSTRAINT_LDS_DOUBLES = 1024 + 1024 + 64 * 65 + 64 * 64 + 1024 + CMAT_DOUBLES + 8;
+// LDS carve (doubles): vn1[nv] vn2[nv] ybuf[nv] blk[blkd] gl[gld] mat[matd] + ints, sized by the host to the problem
+// (small problems then run several workgroups per CU).  blk: 64 x 65 diagonal block of the triangular solves, the
+// 32 x 65 staging chunk of V and the 64-strided T image; gl: 64-strided Gram matrix of one reflector block.
+inline void constraint_carve(long long n, long long t, int fa_done, int& nv, int& blkd, int& gld, int& matd) {
+    const long long mx = n > t ? n : t;
+    const long long kA = n < t ? n : t;
+    nv = (int)((mx + 7) / 8 * 8);
+    blkd = mx <= 32 ? 32 * 65 : 64 * 65;
+    gld = (fa_done || kA == 0) ? 0 : (int)(64 * (kA < 64 ? kA : 64));
+    long long md = n * t > t * kA ? n * t : t * kA;
+    if (md > CMAT_DOUBLES) md = CMAT_DOUBLES;
+    matd = (int)((md + 1) / 2 * 2);
+}
+inline size_t constraint_lds_bytes(int nv, int blkd, int gld, int matd) { return (size_t)(3 * nv + blkd + gld + matd + 8) * 8; }
 
-template <int RPL, int G>
-__global__ __launch_bounds__(1024) void k_constraint(ConstraintArgs a) {
+template <int RPL, int G, int NTH>
+__global__ __launch_bounds__(NTH) void k_constraint(ConstraintArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* vn1 = smem;
-    double* vn2 = vn1 + 1024;
-    double* blk = vn2 + 1024;
-    double* gl = blk + 64 * 65;
-    double* ybuf = gl + 64 * 64;
-    double* mat = ybuf + 1024;
-    int* sh_i = reinterpret_cast<int*>(mat + CMAT_DOUBLES);
+    double* vn2 = vn1 + a.nv;
+    double* ybuf = vn2 + a.nv;
+    double* blk = ybuf + a.nv;
+    double* gl = blk + a.blkd;
+    double* mat = gl + a.gld;
+    int* sh_i = reinterpret_cast<int*>(mat + a.matd);
 
     const int prob = blockIdx.x + a.prob0;
     const int n = a.n, t = a.t, kA = a.kA;
@@ -146,8 +159,11 @@ __global__ __launch_bounds__(1024) void k_constraint(ConstraintArgs a) {
     for (int blkid = 0; blkid < nblk; ++blkid) {
         const int c0 = blkid * KBLK;
         const int kb = (kA - c0) < KBLK ? (kA - c0) : KBLK;
-        const int c1 = tid & 63, c2q = tid >> 6;  // 1024 threads: c2 = c2q + 16 q
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        constexpr int NWV = NTH / 64, NQ = 64 / NWV;
+        const int c1 = tid & 63, c2q = tid >> 6;  // c2 = c2q + NWV q
+        double acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
         for (int row0 = c0; row0 < n; row0 += 32) {
             for (int e = tid; e < 32 * KBLK; e += nt) {
                 const int r = e & 31, c = e >> 5;
@@ -157,20 +173,19 @@ __global__ __launch_bounds__(1024) void k_constraint(ConstraintArgs a) {
                 blk[r * 65 + c] = v;
             }
             __syncthreads();
-            if (tid < 1024) {
-                for (int r = 0; r < 32; ++r) {
-                    const double x1 = blk[r * 65 + c1];
+            for (int r = 0; r < 32; ++r) {
+                const double x1 = blk[r * 65 + c1];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] += x1 * blk[r * 65 + c2q + 16 * q];
-                }
+                for (int q = 0; q < NQ; ++q) acc[q] += x1 * blk[r * 65 + c2q + NWV * q];
             }
             __syncthreads();
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gl[c1 + 64 * (c2q + 16 * q)] = acc[q];
+        for (int q = 0; q < NQ; ++q)
+            if (c2q + NWV * q < kb) gl[c1 + 64 * (c2q + NWV * q)] = acc[q];
         __syncthreads();
-        // T in LDS (blk reused, 64 x 64, ld 64)
-        for (int e = tid; e < KBLK * KBLK; e += nt) blk[e] = 0.0;
+        // T in LDS (blk reused, columns 0..kb-1 of a 64-strided image)
+        for (int e = tid; e < KBLK * kb; e += nt) blk[e] = 0.0;
         __syncthreads();
         for (int j = 0; j < kb; ++j) {
             const double tj = tauA[c0 + j];
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_constraint(ConstraintArgs a) {
             __syncthreads();
         }
         double* T = TA + (size_t)blkid * KBLK * KBLK;
-        for (int e = tid; e < KBLK * KBLK; e += nt) T[e] = blk[e];
+        for (int e = tid; e < KBLK * KBLK; e += nt) T[e] = (e < KBLK * kb) ? blk[e] : 0.0;
         __syncthreads();
     }
 

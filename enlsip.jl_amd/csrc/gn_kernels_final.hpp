@@ -20,6 +20,7 @@ struct FinalArgs {
     int refactor;         // 1: extract R0 and factor it here; 2: Rt already factored (distributed path);
                           // 0: reuse resident Rt (resolve path)
     int prob0;            // problem index offset
+    int nv, matd;         // LDS carve: vector length (>= max(n, t)) and matrix/diagonal-block area in doubles
     const double* dsrc;   // refactor == 0: transformed right-hand side Q3'd (length m, one problem)
     const double* W;   long long sW;      // ldw x (n+1): R0 in the upper triangle of the J2 columns, d in column n
     double* Rt;        long long sRt;     // ldr x (n2max + 1) : pivoted factors + carried rhs
@@ -40,19 +41,31 @@ struct FinalArgs {
     ProbState* state;
 };
 
-// LDS (doubles): vn1[1024] vn2[1024] blk[64*65] ybuf[1024] pbuf[1024] mat[8192] + ints
-constexpr int FINAL_LDS_DOUBLES = 1024 + 1024 + 64 * 65 + 1024 + 1024 + CMAT_DOUBLES + 8;
+// LDS (doubles): vn1[nv] vn2[nv] ybuf[nv] pbuf[nv] mat[matd] + ints, sized by the host to the problem so that small
+// problems run several workgroups per CU.  The 64 x 65 diagonal block of the triangular solve aliases `mat`, which is
+// dead once the pivoted factors have been copied back.
+inline void final_carve(long long m, long long n, long long t, int& nv, int& matd) {
+    const long long mx = n > t ? n : t;
+    nv = (int)((mx + 7) / 8 * 8);
+    const long long kp = m < n ? m : n;
+    long long md = kp * (n + 1);
+    if (md > CMAT_DOUBLES) md = CMAT_DOUBLES;
+    const long long nb = mx < 64 ? mx : 64;
+    if (md < nb * 65) md = nb * 65;
+    matd = (int)((md + 1) / 2 * 2);
+}
+inline size_t final_lds_bytes(int nv, int matd) { return (size_t)(4 * nv + matd + 8) * 8; }
 
-template <int RPL, int G>
-__global__ __launch_bounds__(1024) void k_pivot_solve(FinalArgs a) {
+template <int RPL, int G, int NTH>
+__global__ __launch_bounds__(NTH) void k_pivot_solve(FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* vn1 = smem;
-    double* vn2 = vn1 + 1024;
-    double* blk = vn2 + 1024;
-    double* ybuf = blk + 64 * 65;
-    double* pbuf = ybuf + 1024;
-    double* mat = pbuf + 1024;
-    int* sh_i = reinterpret_cast<int*>(mat + CMAT_DOUBLES);
+    double* vn2 = vn1 + a.nv;
+    double* ybuf = vn2 + a.nv;
+    double* pbuf = ybuf + a.nv;
+    double* mat = pbuf + a.nv;
+    double* blk = mat;
+    int* sh_i = reinterpret_cast<int*>(mat + a.matd);
 
     const int prob = blockIdx.x + a.prob0;
     ProbState* stp = a.state + prob;

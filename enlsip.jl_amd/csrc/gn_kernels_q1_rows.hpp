@@ -1,0 +1,73 @@
+// J * F_A.Q for SMALL problems (src/enlsip_functions.jl:219), fused with d_temp = -J1 p1 - rx (:134 / :145):
+// n <= 64 parameters and at most 16 reflectors (the batched configurations C3: n = 64, t = 8 and C5: n = 32, t = 4).
+// One lane owns one ROW of J in registers and multiplies it by H_0 H_1 ... H_{kA-1} reflector by reflector; the
+// reflectors sit in LDS and are read by broadcast.  Loads and stores run with lanes along rows (coalesced for
+// column-major J); there is no reduction across lanes and one barrier.  The compact-WY kernels (gn_kernels_q1_v2.hpp,
+// gn_kernels_q1_mfma.hpp) pad every block to 64 reflectors, which costs 8-16x the arithmetic at these sizes.
+#pragma once
+#include "gn_kernels_q1.hpp"
+
+namespace gn {
+
+constexpr int Q1R_MAXK = 16;
+
+template <int NMAX>
+__global__ __launch_bounds__(256) void k_jq1_rows(JQ1Args a) {
+    __shared__ __attribute__((aligned(16))) double Vs[Q1R_MAXK * NMAX];   // Vs[k][c] = v_k[c] (unit diagonal, zeros above)
+    __shared__ double taus[Q1R_MAXK];
+    __shared__ double p1s[NMAX];
+    const int n = a.n, m = a.m, kA = a.kA, ldw = a.ldw;
+    const int prob = blockIdx.y + a.prob0;
+    const double* Jin = a.J + prob * a.strideJ;
+    const double* rx = a.rx + prob * a.stride_rx;
+    const double* FA = a.FA + prob * a.sFA;
+    const double* TA = a.TA + prob * a.sTA;
+    const double* p1 = a.p1 + prob * a.sP1;
+    double* W = a.W + prob * a.sW;
+    const int rankA = a.state[prob].rankA;
+    const int tid = threadIdx.x;
+
+    for (int e = tid; e < kA * NMAX; e += 256) {
+        const int k = e / NMAX, c = e % NMAX;
+        double v = 0.0;
+        if (c < n) v = (c > k) ? FA[c + (size_t)k * n] : (c == k ? 1.0 : 0.0);
+        Vs[e] = v;
+    }
+    if (tid < kA) taus[tid] = TA[tid + tid * KBLK];       // dlarft: diag(T) = tau
+    if (tid < NMAX) p1s[tid] = (tid < rankA) ? p1[tid] : 0.0;
+    __syncthreads();
+
+    const int row = blockIdx.x * 256 + tid;
+    if (row >= ldw) return;
+    const bool live = row < m;
+    double x[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) x[c] = (live && c < n) ? __builtin_nontemporal_load(&Jin[row + (size_t)c * a.ldj]) : 0.0;
+    for (int k = 0; k < kA; ++k) {
+        const double* vk = Vs + k * NMAX;
+        double dot = 0.0;
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) dot += x[c] * vk[c];
+        const double s = taus[k] * dot;
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) x[c] -= s * vk[c];
+    }
+    double ds = 0.0;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) ds += x[c] * p1s[c];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c)
+        if (c < n) W[row + (size_t)c * ldw] = x[c];
+    W[row + (size_t)n * ldw] = live ? (-ds - rx[row]) : 0.0;
+}
+
+// Returns false when the shape is outside this kernel's range (the caller falls through to the compact-WY kernels).
+inline bool launch_jq1_rows(const JQ1Args& a, int batch, hipStream_t s) {
+    if (a.n > 64 || a.kA > Q1R_MAXK || getenv("ENLSIP_GN_JQ1_NOROWS")) return false;
+    const dim3 grid((a.ldw + 255) / 256, batch);
+    if (a.n <= 32) hipLaunchKernelGGL(k_jq1_rows<32>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_jq1_rows<64>, grid, dim3(256), 0, s, a);
+    return true;
+}
+
+}  // namespace gn

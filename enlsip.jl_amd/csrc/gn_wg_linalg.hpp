@@ -125,44 +125,63 @@ __device__ void wg_geqp2(double* __restrict__ A, int ld, int rows, int cols, int
                     dot[g] += a[g][i] * v[i];
                 }
             }
+            if constexpr (G == 8 || G == 4) {
+                double red[G];
+                wave_allsumN(dot, red);      // G reductions in one transposed butterfly
 #pragma unroll
-            for (int g = 0; g < G; ++g) dot[g] = wave_allsum(dot[g]);
+                for (int g = 0; g < G; ++g) dot[g] = red[g];
+            } else {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int c = cbase + g;
-                if (c >= ctot) continue;
-                if (h.tau != 0.0) {
+                for (int g = 0; g < G; ++g) dot[g] = wave_allsum(dot[g]);
+            }
+            if (h.tau != 0.0) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int c = cbase + g;
                     const double wd = h.tau * dot[g];
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) {
                         const int r = j + ln + WAVE * i;
                         a[g][i] -= wd * v[i];
-                        if (r < rows) A[r + (size_t)c * ld] = a[g][i];
+                        if (c < ctot && r < rows) A[r + (size_t)c * ld] = a[g][i];
                     }
                 }
-                if (c < cols) {
-                    // norm downdate (dlaqp2); uniform across the wave
-                    const double ajc = wave_bcast(a[g][0], 0);
-                    const double o1 = vn1[c], o2 = vn2[c];
-                    if (o1 != 0.0) {
-                        double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
-                        temp = temp > 0.0 ? temp : 0.0;
-                        const double q = o1 / o2;
-                        const double temp2 = temp * q * q;
-                        if (temp2 <= tol3z) {
-                            double s = 0.0;
+            }
+            // norm downdate (dlaqp2) of the G columns at once: lane g owns column cbase + g (the divisions and the
+            // square root are issued once per sweep instead of once per column)
+            double ajl = 0.0;
 #pragma unroll
-                            for (int i = 0; i < RPL; ++i)
-                                if (ln + WAVE * i > 0) s += a[g][i] * a[g][i];
-                            s = wave_allsum(s);
-                            const double nv = (j + 1 < rows) ? sqrt(s) : 0.0;
-                            if (ln == 0) {
-                                vn1[c] = nv;
-                                vn2[c] = nv;
-                            }
-                        } else if (ln == 0) {
-                            vn1[c] = o1 * sqrt(temp);
-                        }
+            for (int g = 0; g < G; ++g) {
+                const double x = wave_bcast(a[g][0], 0);
+                ajl = (ln == g) ? x : ajl;
+            }
+            bool need = false;
+            const int cl = cbase + ln;
+            if (ln < G && cl < cols) {
+                const double o1 = vn1[cl], o2 = vn2[cl];
+                if (o1 != 0.0) {
+                    double temp = 1.0 - (fabs(ajl) / o1) * (fabs(ajl) / o1);
+                    temp = temp > 0.0 ? temp : 0.0;
+                    const double q = o1 / o2;
+                    const double temp2 = temp * q * q;
+                    if (temp2 <= tol3z) need = true;
+                    else vn1[cl] = o1 * sqrt(temp);
+                }
+            }
+            const unsigned long long redo = __ballot(need);
+            if (redo) {   // rare: recompute the partial norm from the updated column
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (!((redo >> g) & 1ull)) continue;
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i)
+                        if (ln + WAVE * i > 0) s += a[g][i] * a[g][i];
+                    s = wave_allsum(s);
+                    const double nv = (j + 1 < rows) ? sqrt(s) : 0.0;
+                    if (ln == 0) {
+                        vn1[cbase + g] = nv;
+                        vn2[cbase + g] = nv;
                     }
                 }
             }
