@@ -18,6 +18,7 @@
 #include "gn_kernels_q1_mfma.hpp"
 #include "gn_kernels_q1_v2.hpp"
 #include "gn_kernels_q1_rows.hpp"
+#include "gn_kernels_final_small.hpp"
 #include "gn_kernels_update_v4.hpp"
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_lagrange.hpp"
@@ -536,7 +537,8 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
                 fa.refactor = 2;
             }
         }
-        launch_pivot((int)std::min<long long>(m, n), (int)batch, s, fa);
+        if (!launch_pivot_small((int)std::min<long long>(m, n2_launch), n2_launch, (int)batch, s, fa))
+            launch_pivot((int)std::min<long long>(m, n), (int)batch, s, fa);
         mark(4);
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));

@@ -1,0 +1,263 @@
+// Pivot + solve stage for SMALL factors (kp <= 64 rows, n2 + 1 <= 64 columns): ONE WAVE per problem, no barriers.
+// Same contract as k_pivot_solve (gn_kernels_final.hpp, refactor == 1):
+//   R0 P = Qt Rt, rankJ2 = pseudo_rank(diag Rt)         src/enlsip_functions.jl:223-224
+//   dp2 = U(Rt) \ d[1:dimJ2], p2 = [dp2;0][invperm]     :136-137 / :147-148
+//   p = F_A.Q [p1; p2]                                   :151
+//
+// Layout: lane c owns COLUMN c of [R0 | z] (lane n2 = the carried right-hand side), its rows live in registers.
+// A pivot step is then lane-local except for three things: the arg-max over the partial norms (one DPP butterfly),
+// the broadcast of the Householder vector (the pivot lane writes it to LDS, every lane reads it back by broadcast)
+// and three scalars (v_readlane).  Column norms, dot products, updates and the dlaqp2 norm downdates need no
+// reduction at all, where the workgroup form (wg_geqp2, lanes along rows) pays a wave reduction per column per step
+// and four barriers per step.  Columns are never swapped: every lane tracks its LAPACK position, which also
+// reproduces jpvt of the columns that never become pivots.
+//
+// Register rows are addressed statically: the step loop runs in blocks of eight unrolled sub-steps, after which the
+// rows shift up by eight; finished rows (R entries) are parked in a wave-private LDS image [row][lane].
+#pragma once
+#include "gn_kernels_final.hpp"
+
+namespace gn {
+
+// LDS (doubles): tmp[kpm * 65] vbuf[64] dg[64] pbuf[nv]
+inline size_t final_small_lds_bytes(int kpm, int nv) { return (size_t)(kpm * 65 + 64 + 64 + nv + 8) * 8; }
+
+template <int NR, int S>
+__device__ __forceinline__ void pivot_small_substep(double (&x)[NR], const int j, const int kp, const int n2, const int rem,
+                                                    const int ln, int& mypos, double& vn1, double& vn2,
+                                                    double* __restrict__ tmp, double* __restrict__ vbuf,
+                                                    double* __restrict__ dg, double* __restrict__ Rtcol,
+                                                    double* __restrict__ tauJ) {
+    const double tol3z = 1.4901161193847656e-08;  // sqrt(eps), dlaqp2
+    // (a) pivot = first position of the largest partial norm among the unprocessed columns
+    const bool cand = (ln < n2) && (mypos >= j);
+    const ArgMax am = wave_argmax(cand ? vn1 : -1.0, mypos, ln);
+    const int pl = am.idx, pp = am.pos;
+    // (b) LAPACK's swap of positions j <-> pp
+    if (mypos == j) mypos = pp;
+    if (ln == pl) mypos = j;
+    // (c) reflector of the pivot column (every lane evaluates its own column; only lane pl's is used)
+    double xn2 = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < NR / 8; ++ch) {
+        if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = 8 * ch + rr;
+                if (r > S) xn2 += x[r] * x[r];
+            }
+        }
+    }
+    const Reflector hme = make_reflector(x[S], xn2);
+    const double beta = wave_bcast(hme.beta, pl), tau = wave_bcast(hme.tau, pl), scale = wave_bcast(hme.scale, pl);
+    if (ln == pl) {
+        x[S] = beta;
+#pragma unroll
+        for (int ch = 0; ch < NR / 8; ++ch) {
+            if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * ch + rr;
+                    if (r > S) {
+                        x[r] *= scale;
+                        vbuf[r] = x[r];
+                    }
+                }
+            }
+        }
+    }
+    // (d) apply H_j to the unprocessed columns and the right-hand side
+    const bool upd = (mypos > j) && (ln <= n2);
+    if (upd && tau != 0.0) {
+        double dot = x[S];
+#pragma unroll
+        for (int ch = 0; ch < NR / 8; ++ch) {
+            if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * ch + rr;
+                    if (r > S) dot += x[r] * vbuf[r];
+                }
+            }
+        }
+        const double wd = tau * dot;
+        x[S] -= wd;
+#pragma unroll
+        for (int ch = 0; ch < NR / 8; ++ch) {
+            if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * ch + rr;
+                    if (r > S) x[r] -= wd * vbuf[r];
+                }
+            }
+        }
+    }
+    // (e) row j is final in every column at a position >= j; the Householder vector goes to column j of Rt
+    if (mypos >= j && ln <= n2) tmp[j * 65 + ln] = x[S];
+    if (ln == 0) {
+        tauJ[j] = tau;
+        dg[j] = beta;
+    }
+    {
+        const int q = ln;   // row j + 1 + q  <-  block-relative row S + 1 + q
+        if (j + 1 + q < kp) Rtcol[j + 1 + q] = vbuf[S + 1 + q];
+    }
+    // (f) dlaqp2 norm downdate, lane-local
+    if (upd && ln < n2 && vn1 != 0.0) {
+        const double ajc = x[S];
+        double temp = 1.0 - (fabs(ajc) / vn1) * (fabs(ajc) / vn1);
+        temp = temp > 0.0 ? temp : 0.0;
+        const double q = vn1 / vn2;
+        const double temp2 = temp * q * q;
+        if (temp2 <= tol3z) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NR / 8; ++ch) {
+                if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = 8 * ch + rr;
+                        if (r > S) s2 += x[r] * x[r];
+                    }
+                }
+            }
+            const double nv = (j + 1 < kp) ? sqrt(s2) : 0.0;
+            vn1 = nv;
+            vn2 = nv;
+        } else {
+            vn1 *= sqrt(temp);
+        }
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int prob = blockIdx.x + a.prob0;
+    ProbState* stp = a.state + prob;
+    const int rankA = stp->rankA, n2 = stp->n2, kp = stp->kp;
+    // a problem whose J2 is wider than the launch shape (rank-deficient A) is redone by the caller with the true width
+    if (kp > NR || n2 + 1 > 64 || kp * 65 > a.matd) return;
+    double* tmp = smem;
+    double* vbuf = tmp + a.matd;
+    double* dg = vbuf + 64;
+    double* pbuf = dg + 64;
+    const int n = a.n, m = a.m, t = a.t, kA = a.kA, ldr = a.ldr, ldw = a.ldw;
+    const double* W = a.W + prob * a.sW;
+    double* Rt = a.Rt + prob * a.sRt;
+    double* tauJ = a.tauJ + prob * a.sTauJ;
+    long long* jpvtJ = a.jpvtJ + prob * a.sJJ;
+    const double* FA = a.FA + prob * a.sFA;
+    const double* tauA = a.tauA + prob * a.sTauA;
+    const double* p1 = a.p1 + prob * a.sP1;
+    const double* bvec = a.bvec + prob * a.sB;
+    const int ln = threadIdx.x;
+    int status = 0;
+
+    // ---- R0 (upper trapezoid) and z: columns through LDS so that the global loads run along rows ---------------
+    for (int c = 0; c <= n2; ++c) {
+        if (ln < kp) {
+            double v;
+            if (c < n2) v = (ln <= c) ? W[ln + (size_t)(rankA + c) * ldw] : 0.0;
+            else v = W[ln + (size_t)n * ldw];
+            tmp[ln * 65 + c] = v;
+        }
+    }
+    if (a.zsave && ln < kp) a.zsave[prob * a.sZ + ln] = W[ln + (size_t)n * ldw];
+    double x[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) x[r] = (r < kp && ln <= n2) ? tmp[r * 65 + ln] : 0.0;
+    double vn1;
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) s += x[r] * x[r];
+        vn1 = sqrt(s);
+    }
+    double vn2 = vn1;
+    int mypos = ln;
+
+    // ---- pivoted QR, eight unrolled steps per block, rows shifted up between blocks ------------------------------
+    for (int jb = 0; 8 * jb < kp; ++jb) {
+        const int j0 = 8 * jb, rem = kp - j0;
+#define GN_PS_STEP(S)                                                                                                   \
+    if (j0 + S < kp)                                                                                                    \
+        pivot_small_substep<NR, S>(x, j0 + S, kp, n2, rem, ln, mypos, vn1, vn2, tmp, vbuf, dg, Rt + (size_t)(j0 + S) * ldr, tauJ);
+        GN_PS_STEP(0) GN_PS_STEP(1) GN_PS_STEP(2) GN_PS_STEP(3) GN_PS_STEP(4) GN_PS_STEP(5) GN_PS_STEP(6) GN_PS_STEP(7)
+#undef GN_PS_STEP
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] = (r + 8 < NR) ? x[(r + 8 < NR) ? r + 8 : r] : 0.0;
+    }
+
+    // ---- permutation, upper parts of the columns, rank ---------------------------------------------------------------
+    if (ln < n2) jpvtJ[mypos] = ln + 1;
+    // lane-of-position table (positions 0..n2): lp of lane i = lane that sits at position i
+    int* lpos = reinterpret_cast<int*>(vbuf);
+    if (ln <= n2) lpos[mypos] = ln;
+    const int lp = (ln <= n2) ? lpos[ln] : 0;
+    for (int P = 0; P <= n2; ++P) {
+        const int src = __builtin_amdgcn_readlane(lp, P);
+        if (ln < kp && ln <= P) Rt[ln + (size_t)P * ldr] = tmp[ln * 65 + src];
+    }
+    int rankJ2 = 0;
+    if (kp > 0) {
+        const double d0 = fabs(dg[0]);
+        if (!(d0 < a.eps_rank)) {
+            const double tol = d0 * sqrt((double)kp) * a.eps_rank;
+            const bool fail = (ln < kp) && !(fabs(dg[ln < kp ? ln : 0]) > tol);
+            const unsigned long long mk = __ballot(fail);
+            rankJ2 = mk ? (int)__builtin_ctzll(mk) : kp;
+        }
+    }
+    const int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
+
+    // ---- dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]: lane r carries row r of the right-hand side ------------------------
+    double zw = (ln < dimJ2 && ln < kp) ? tmp[ln * 65 + n2] : 0.0;
+    for (int i = (dimJ2 < kp ? dimJ2 : kp) - 1; i >= 0; --i) {
+        const int li = __builtin_amdgcn_readlane(lp, i);
+        const double dkk = tmp[i * 65 + li];
+        if (dkk == 0.0) status |= 1;
+        const double yi = wave_bcast(zw, i) / dkk;
+        if (ln == i) zw = yi;
+        if (ln < i) zw -= tmp[ln * 65 + li] * yi;
+    }
+    // y = [p1 ; p2],  p2[pJ[i]-1] = (i < dimJ2 ? dp2[i] : 0)
+    for (int i = ln; i < rankA; i += WAVE) pbuf[i] = p1[i];
+    if (ln < n2) pbuf[rankA + lp] = (ln < dimJ2) ? zw : 0.0;
+    // p = F_A.Q * y
+    wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);
+    if (a.p_out)
+        for (int i = ln; i < n; i += WAVE) a.p_out[prob * a.sPo + i] = pbuf[i];
+    if (a.b_out)
+        for (int i = ln; i < t; i += WAVE) a.b_out[prob * a.sBo + i] = bvec[i];
+    if (a.d_out) {
+        for (int i = ln; i < m; i += WAVE)
+            a.d_out[prob * a.sDo + i] = (i < kp) ? tmp[i * 65 + n2] : W[i + (size_t)n * ldw];
+    }
+    if (a.jA_out)
+        for (int i = ln; i < t; i += WAVE) a.jA_out[prob * a.sJAo + i] = a.jpvtA[prob * a.sJA + i];
+    if (a.jL_out)
+        for (int i = ln; i < kA; i += WAVE) a.jL_out[prob * a.sJLo + i] = a.jpvtL[prob * a.sJL + i];
+    if (a.jJ_out && ln < n2) a.jJ_out[prob * a.sJJo + mypos] = ln + 1;
+    if (ln == 0) {
+        stp->rankJ2 = rankJ2;
+        stp->dimJ2 = dimJ2;
+        stp->status |= status;
+    }
+}
+
+// Returns false when the launch shape is outside the kernel's range (the caller uses k_pivot_solve).
+inline bool launch_pivot_small(int kp_launch, int n2_launch, int batch, hipStream_t s, FinalArgs a) {
+    if (kp_launch > 64 || n2_launch + 1 > 64 || a.refactor != 1 || a.dsrc || getenv("ENLSIP_GN_PIVOT_WG")) return false;
+    const long long mx = a.n > a.t ? a.n : a.t;
+    a.nv = (int)((mx + 7) / 8 * 8);
+    a.matd = (kp_launch > 0 ? kp_launch : 1) * 65 + 1;
+    a.matd = (a.matd + 1) / 2 * 2;
+    const size_t lds = final_small_lds_bytes(0, a.nv) + (size_t)a.matd * 8;
+    if (kp_launch <= 32) hipLaunchKernelGGL(k_pivot_small<32>, dim3(batch), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL(k_pivot_small<64>, dim3(batch), dim3(64), lds, s, a);
+    return true;
+}
+
+}  // namespace gn
