@@ -19,6 +19,7 @@
 #include "gn_kernels_q1_v2.hpp"
 #include "gn_kernels_q1_rows.hpp"
 #include "gn_kernels_final_small.hpp"
+#include "gn_kernels_constraint_small.hpp"
 #include "gn_kernels_update_v4.hpp"
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_lagrange.hpp"
@@ -183,6 +184,7 @@ static void big_lds(KernelT k, size_t bytes) {
 // Problems with at most 64 rows run with 256 or 512 threads and an LDS carve sized to the problem, so that batches of
 // small problems (C3, C5) keep several workgroups resident per CU; larger ones use 1024 threads.
 static void launch_constraint(int rows, int batch, hipStream_t s, ConstraintArgs a) {
+    if (launch_constraint_small(batch, s, a)) return;
     constraint_carve(a.n, a.t, a.fa_done, a.nv, a.blkd, a.gld, a.matd);
     const size_t lds = constraint_lds_bytes(a.nv, a.blkd, a.gld, a.matd);
     if (rows <= 32) GN_LAUNCH_BIG((k_constraint<1, 8, 256>), dim3(batch), dim3(256), lds, s, a);
@@ -254,10 +256,13 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     for (int k = 0; k < npan; ++k) {
         const int bwk = std::min(PB, kp_launch - k * PB);
         const int ntrail = n2_launch + 1 - (k * PB + bwk);  // trailing columns incl. the augmented one
+        // last panel narrower than 32 with d as the only trailing column: d rides through the factor kernels
+        const bool passenger = (ntrail == 1 && bwk < PB && kp_launch == n2_launch && !getenv("ENLSIP_GN_NO_PASSENGER"));
         for (const LevelPlan& L : P.panels[k].levels) {
             CaqrArgs a = caqr_args(h, k, L);
+            a.npass = passenger ? 1 : 0;
             launch_factor(h, a, L.groups);
-            if (ntrail > 0) {
+            if (ntrail > 0 && !passenger) {
                 const bool lvl0 = (L.level == 0);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->profiling && lvl0) {

@@ -39,6 +39,9 @@ struct CaqrArgs {
     double* C;          long long sC;
     int reverse;        // 1: apply reflectors in reverse order (Q instead of Q')
     int prob0;          // problem index offset (accessors address one problem of a batch)
+    int npass;          // factor kernel: 1 = the column right after a panel narrower than 32 (the carried right-hand side
+                        // d, when it is the ONLY trailing column) rides through the factorisation as a passenger: it receives
+                        // every reflector but is never factored, and no trailing-update launch is needed for the panel
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
     const int r0 = a.panel * PB;
     if (r0 >= st.kp) return;
     const int bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
+    const int bwp = (a.npass && bw < PB) ? bw + 1 : bw;      // panel columns + passenger
     const int col0 = st.rankA + r0;
     const int g = blockIdx.x;
     const int ln = lane_id();
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
         const int c = w + NW * cc;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const bool ok = (c < bw) && bval(i) && (!tri || rb <= c);
+            // tree levels hold upper triangles; the passenger has entries in every row a reflector touches
+            const bool ok = (c < bwp) && bval(i) && (!tri || (c < bw ? rb <= c : rb < bw));
             x[cc][i] = ok ? W[ubase(c, i) + lane_off] : 0.0;
         }
     }
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : 2) void k_c
         const int c = w + NW * cc;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const bool ok = (c < bw) && bval(i) && (!tri || rb <= c);
+            const bool ok = (c < bwp) && bval(i) && (!tri || (c < bw ? rb <= c : rb < bw));
             if (ok) W[ubase(c, i) + lane_off] = x[cc][i];
         }
     }

@@ -4,132 +4,15 @@
 //   dp2 = U(Rt) \ d[1:dimJ2], p2 = [dp2;0][invperm]     :136-137 / :147-148
 //   p = F_A.Q [p1; p2]                                   :151
 //
-// Layout: lane c owns COLUMN c of [R0 | z] (lane n2 = the carried right-hand side), its rows live in registers.
-// A pivot step is then lane-local except for three things: the arg-max over the partial norms (one DPP butterfly),
-// the broadcast of the Householder vector (the pivot lane writes it to LDS, every lane reads it back by broadcast)
-// and three scalars (v_readlane).  Column norms, dot products, updates and the dlaqp2 norm downdates need no
-// reduction at all, where the workgroup form (wg_geqp2, lanes along rows) pays a wave reduction per column per step
-// and four barriers per step.  Columns are never swapped: every lane tracks its LAPACK position, which also
-// reproduces jpvt of the columns that never become pivots.
-//
-// Register rows are addressed statically: the step loop runs in blocks of eight unrolled sub-steps, after which the
-// rows shift up by eight; finished rows (R entries) are parked in a wave-private LDS image [row][lane].
+// Layout: lane c owns COLUMN c of [R0 | z] (lane n2 = the carried right-hand side), rows in registers: gn_wave_qrcp.hpp.
 #pragma once
 #include "gn_kernels_final.hpp"
+#include "gn_wave_qrcp.hpp"
 
 namespace gn {
 
 // LDS (doubles): tmp[kpm * 65] vbuf[64] dg[64] pbuf[nv]
 inline size_t final_small_lds_bytes(int kpm, int nv) { return (size_t)(kpm * 65 + 64 + 64 + nv + 8) * 8; }
-
-template <int NR, int S>
-__device__ __forceinline__ void pivot_small_substep(double (&x)[NR], const int j, const int kp, const int n2, const int rem,
-                                                    const int ln, int& mypos, double& vn1, double& vn2,
-                                                    double* __restrict__ tmp, double* __restrict__ vbuf,
-                                                    double* __restrict__ dg, double* __restrict__ Rtcol,
-                                                    double* __restrict__ tauJ) {
-    const double tol3z = 1.4901161193847656e-08;  // sqrt(eps), dlaqp2
-    // (a) pivot = first position of the largest partial norm among the unprocessed columns
-    const bool cand = (ln < n2) && (mypos >= j);
-    const ArgMax am = wave_argmax(cand ? vn1 : -1.0, mypos, ln);
-    const int pl = am.idx, pp = am.pos;
-    // (b) LAPACK's swap of positions j <-> pp
-    if (mypos == j) mypos = pp;
-    if (ln == pl) mypos = j;
-    // (c) reflector of the pivot column (every lane evaluates its own column; only lane pl's is used)
-    double xn2 = 0.0;
-#pragma unroll
-    for (int ch = 0; ch < NR / 8; ++ch) {
-        if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = 8 * ch + rr;
-                if (r > S) xn2 += x[r] * x[r];
-            }
-        }
-    }
-    const Reflector hme = make_reflector(x[S], xn2);
-    const double beta = wave_bcast(hme.beta, pl), tau = wave_bcast(hme.tau, pl), scale = wave_bcast(hme.scale, pl);
-    if (ln == pl) {
-        x[S] = beta;
-#pragma unroll
-        for (int ch = 0; ch < NR / 8; ++ch) {
-            if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = 8 * ch + rr;
-                    if (r > S) {
-                        x[r] *= scale;
-                        vbuf[r] = x[r];
-                    }
-                }
-            }
-        }
-    }
-    // (d) apply H_j to the unprocessed columns and the right-hand side
-    const bool upd = (mypos > j) && (ln <= n2);
-    if (upd && tau != 0.0) {
-        double dot = x[S];
-#pragma unroll
-        for (int ch = 0; ch < NR / 8; ++ch) {
-            if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = 8 * ch + rr;
-                    if (r > S) dot += x[r] * vbuf[r];
-                }
-            }
-        }
-        const double wd = tau * dot;
-        x[S] -= wd;
-#pragma unroll
-        for (int ch = 0; ch < NR / 8; ++ch) {
-            if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = 8 * ch + rr;
-                    if (r > S) x[r] -= wd * vbuf[r];
-                }
-            }
-        }
-    }
-    // (e) row j is final in every column at a position >= j; the Householder vector goes to column j of Rt
-    if (mypos >= j && ln <= n2) tmp[j * 65 + ln] = x[S];
-    if (ln == 0) {
-        tauJ[j] = tau;
-        dg[j] = beta;
-    }
-    {
-        const int q = ln;   // row j + 1 + q  <-  block-relative row S + 1 + q
-        if (j + 1 + q < kp) Rtcol[j + 1 + q] = vbuf[S + 1 + q];
-    }
-    // (f) dlaqp2 norm downdate, lane-local
-    if (upd && ln < n2 && vn1 != 0.0) {
-        const double ajc = x[S];
-        double temp = 1.0 - (fabs(ajc) / vn1) * (fabs(ajc) / vn1);
-        temp = temp > 0.0 ? temp : 0.0;
-        const double q = vn1 / vn2;
-        const double temp2 = temp * q * q;
-        if (temp2 <= tol3z) {
-            double s2 = 0.0;
-#pragma unroll
-            for (int ch = 0; ch < NR / 8; ++ch) {
-                if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) {
-                        const int r = 8 * ch + rr;
-                        if (r > S) s2 += x[r] * x[r];
-                    }
-                }
-            }
-            const double nv = (j + 1 < kp) ? sqrt(s2) : 0.0;
-            vn1 = nv;
-            vn2 = nv;
-        } else {
-            vn1 *= sqrt(temp);
-        }
-    }
-}
 
 template <int NR>
 __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
@@ -168,27 +51,11 @@ __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
     double x[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) x[r] = (r < kp && ln <= n2) ? tmp[r * 65 + ln] : 0.0;
-    double vn1;
-    {
-        double s = 0.0;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) s += x[r] * x[r];
-        vn1 = sqrt(s);
-    }
-    double vn2 = vn1;
+    WaveQrcp q{};
+    q.rows = kp; q.k = kp; q.ncand = n2; q.npart = n2 + 1;
+    q.tmp = tmp; q.vbuf = vbuf; q.dg = dg; q.F = Rt; q.ldf = ldr; q.tau = tauJ;
     int mypos = ln;
-
-    // ---- pivoted QR, eight unrolled steps per block, rows shifted up between blocks ------------------------------
-    for (int jb = 0; 8 * jb < kp; ++jb) {
-        const int j0 = 8 * jb, rem = kp - j0;
-#define GN_PS_STEP(S)                                                                                                   \
-    if (j0 + S < kp)                                                                                                    \
-        pivot_small_substep<NR, S>(x, j0 + S, kp, n2, rem, ln, mypos, vn1, vn2, tmp, vbuf, dg, Rt + (size_t)(j0 + S) * ldr, tauJ);
-        GN_PS_STEP(0) GN_PS_STEP(1) GN_PS_STEP(2) GN_PS_STEP(3) GN_PS_STEP(4) GN_PS_STEP(5) GN_PS_STEP(6) GN_PS_STEP(7)
-#undef GN_PS_STEP
-#pragma unroll
-        for (int r = 0; r < NR; ++r) x[r] = (r + 8 < NR) ? x[(r + 8 < NR) ? r + 8 : r] : 0.0;
-    }
+    if (kp > 0) wave_qrcp<NR, false>(x, q, ln, mypos);
 
     // ---- permutation, upper parts of the columns, rank ---------------------------------------------------------------
     if (ln < n2) jpvtJ[mypos] = ln + 1;
@@ -196,20 +63,8 @@ __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
     int* lpos = reinterpret_cast<int*>(vbuf);
     if (ln <= n2) lpos[mypos] = ln;
     const int lp = (ln <= n2) ? lpos[ln] : 0;
-    for (int P = 0; P <= n2; ++P) {
-        const int src = __builtin_amdgcn_readlane(lp, P);
-        if (ln < kp && ln <= P) Rt[ln + (size_t)P * ldr] = tmp[ln * 65 + src];
-    }
-    int rankJ2 = 0;
-    if (kp > 0) {
-        const double d0 = fabs(dg[0]);
-        if (!(d0 < a.eps_rank)) {
-            const double tol = d0 * sqrt((double)kp) * a.eps_rank;
-            const bool fail = (ln < kp) && !(fabs(dg[ln < kp ? ln : 0]) > tol);
-            const unsigned long long mk = __ballot(fail);
-            rankJ2 = mk ? (int)__builtin_ctzll(mk) : kp;
-        }
-    }
+    wave_qrcp_store_upper(q, ln, lp, n2 + 1, Rt, ldr);
+    const int rankJ2 = wave_pseudo_rank(dg, kp, a.eps_rank, ln);
     const int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
 
     // ---- dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]: lane r carries row r of the right-hand side ------------------------

@@ -1,0 +1,200 @@
+// Column-pivoted Householder QR (LAPACK dgeqp3 / dlaqp2 semantics) of a SMALL matrix by ONE WAVE:
+// lane c owns COLUMN c, its rows live in registers (at most 64 rows, at most 64 columns including carried right-hand
+// sides).  A pivot step is lane-local except for the arg-max over the partial norms (one DPP butterfly), the broadcast
+// of the Householder vector (the pivot lane writes it to LDS, every lane reads it back by broadcast) and three scalars
+// (v_readlane): column norms, dot products, updates and norm downdates need no reduction, where the workgroup form
+// (wg_geqp2, lanes along rows) pays a wave reduction per column per step and four barriers per step.  Columns are never
+// swapped: every lane tracks its LAPACK position, which also reproduces jpvt of the columns that never become pivots.
+//
+// Register rows are addressed statically: the step loop runs in blocks of eight unrolled sub-steps, after which the
+// rows shift up by eight.  Finished rows (R entries) are parked in a wave-private LDS image tmp[row * 65 + lane]; the
+// Householder vectors go straight to the factor matrix in memory (LAPACK layout, by position).
+//
+// GRAM: also build the dlarft T factor (forward, columnwise; 64-strided LDS image Tl) of the reflectors: the lanes of
+// already processed columns still hold their own v below the diagonal, so the Gram entry v_l' v_j is the same dot
+// product the unprocessed lanes compute for the update.
+#pragma once
+#include "gn_device_utils.hpp"
+
+namespace gn {
+
+struct WaveQrcp {
+    int rows, k;          // matrix rows, number of steps (min(rows, pivot candidates))
+    int ncand, npart;     // lanes [0, ncand) are pivot candidates; lanes [ncand, npart) carried right-hand sides
+    double* tmp;          // LDS: k x 65 finished rows
+    double* vbuf;         // LDS: 64 (current Householder vector, block-relative rows)
+    double* dg;           // LDS: 64 (diagonal of R)
+    double* F;            // factor matrix (LAPACK layout), leading dimension ldf: receives v below the diagonal
+    long long ldf;
+    double* tau;          // k
+    double* Tl;           // GRAM: LDS 64 x k image of T (ld 64);  gcol: LDS 64
+    double* gcol;
+};
+
+template <int NR, int S, bool GRAM>
+__device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrcp& q, const int j, const int rem, const int ln,
+                                                  int& mypos, double& vn1, double& vn2) {
+    const double tol3z = 1.4901161193847656e-08;  // sqrt(eps), dlaqp2
+    // (a) pivot = first position of the largest partial norm among the unprocessed columns
+    const bool cand = (ln < q.ncand) && (mypos >= j);
+    const ArgMax am = wave_argmax(cand ? vn1 : -1.0, mypos, ln);
+    const int pl = am.idx, pp = am.pos;
+    // (b) LAPACK's swap of positions j <-> pp
+    if (mypos == j) mypos = pp;
+    if (ln == pl) mypos = j;
+    // (c) reflector of the pivot column (every lane evaluates its own column; only lane pl's is used)
+    double xn2 = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < NR / 8; ++ch) {
+        if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = 8 * ch + rr;
+                if (r > S) xn2 += x[r] * x[r];
+            }
+        }
+    }
+    const Reflector hme = make_reflector(x[S], xn2);
+    const double beta = wave_bcast(hme.beta, pl), tau = wave_bcast(hme.tau, pl), scale = wave_bcast(hme.scale, pl);
+    if (ln == pl) {
+        x[S] = beta;
+#pragma unroll
+        for (int ch = 0; ch < NR / 8; ++ch) {
+            if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * ch + rr;
+                    if (r > S) {
+                        x[r] *= scale;
+                        q.vbuf[r] = x[r];
+                    }
+                }
+            }
+        }
+    }
+    // (d) apply H_j to the unprocessed columns and the right-hand sides
+    const bool upd = (mypos > j) && (ln < q.npart);
+    const bool gram = GRAM && (mypos < j) && (ln < q.npart);
+    if (upd || gram) {
+        double dot = x[S];
+#pragma unroll
+        for (int ch = 0; ch < NR / 8; ++ch) {
+            if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * ch + rr;
+                    if (r > S) dot += x[r] * q.vbuf[r];
+                }
+            }
+        }
+        if (upd && tau != 0.0) {
+            const double wd = tau * dot;
+            x[S] -= wd;
+#pragma unroll
+            for (int ch = 0; ch < NR / 8; ++ch) {
+                if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = 8 * ch + rr;
+                        if (r > S) x[r] -= wd * q.vbuf[r];
+                    }
+                }
+            }
+        }
+        if (gram) q.gcol[mypos] = dot;       // G[l][j] = v_l' v_j, l = position of this lane's column
+    }
+    if constexpr (GRAM) {
+        // T[0:j, j] = -tau_j T[0:j, 0:j] G[0:j, j]; T[j][j] = tau_j   (lane l builds row l)
+        if (ln < j) {
+            double s = 0.0;
+            for (int i = ln; i < j; ++i) s += q.Tl[ln + 64 * i] * q.gcol[i];
+            q.Tl[ln + 64 * j] = -tau * s;
+        }
+        if (ln == j) q.Tl[j + 64 * j] = tau;
+    }
+    // (e) row j is final in every column at a position >= j; the Householder vector goes to column j of F
+    if (mypos >= j && ln < q.npart) q.tmp[j * 65 + ln] = x[S];
+    if (ln == 0) {
+        q.tau[j] = tau;
+        q.dg[j] = beta;
+    }
+    if (j + 1 + ln < q.rows) q.F[(size_t)j * q.ldf + j + 1 + ln] = q.vbuf[S + 1 + ln];   // row j+1+ln <- block row S+1+ln
+    // (f) dlaqp2 norm downdate, lane-local
+    if (upd && ln < q.ncand && vn1 != 0.0) {
+        const double ajc = x[S];
+        double temp = 1.0 - (fabs(ajc) / vn1) * (fabs(ajc) / vn1);
+        temp = temp > 0.0 ? temp : 0.0;
+        const double qq = vn1 / vn2;
+        const double temp2 = temp * qq * qq;
+        if (temp2 <= tol3z) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NR / 8; ++ch) {
+                if (8 * ch + 7 > S && 8 * ch < rem) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = 8 * ch + rr;
+                        if (r > S) s2 += x[r] * x[r];
+                    }
+                }
+            }
+            const double nv = (j + 1 < q.rows) ? sqrt(s2) : 0.0;
+            vn1 = nv;
+            vn2 = nv;
+        } else {
+            vn1 *= sqrt(temp);
+        }
+    }
+}
+
+// Factorisation driver.  x: the lane's column (rows 0..NR-1, zero beyond q.rows and in idle lanes).  On return mypos is
+// the LAPACK position of the lane's column and the register rows are relative to the returned row offset j0 (the last
+// block is not shifted out, so rows >= k of a carried right-hand side are still in x[row - j0]).
+template <int NR, bool GRAM>
+__device__ __forceinline__ int wave_qrcp(double (&x)[NR], const WaveQrcp& q, const int ln, int& mypos) {
+    double vn1;
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) s += x[r] * x[r];
+        vn1 = sqrt(s);
+    }
+    double vn2 = vn1;
+    mypos = ln;
+    int j0 = 0;
+    for (;;) {
+        const int rem = q.rows - j0;
+#define GN_WQ_STEP(S) \
+    if (j0 + S < q.k) wave_qrcp_substep<NR, S, GRAM>(x, q, j0 + S, rem, ln, mypos, vn1, vn2);
+        GN_WQ_STEP(0) GN_WQ_STEP(1) GN_WQ_STEP(2) GN_WQ_STEP(3) GN_WQ_STEP(4) GN_WQ_STEP(5) GN_WQ_STEP(6) GN_WQ_STEP(7)
+#undef GN_WQ_STEP
+        if (j0 + 8 >= q.k) break;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] = (r + 8 < NR) ? x[(r + 8 < NR) ? r + 8 : r] : 0.0;
+        j0 += 8;
+    }
+    return j0;
+}
+
+// Upper parts of the factor columns from the finished-row image: column at position P, rows <= min(P, k - 1).
+// lp: lane i holds the lane that sits at position i.  ncols: positions written.
+__device__ __forceinline__ void wave_qrcp_store_upper(const WaveQrcp& q, const int ln, const int lp, const int ncols,
+                                                      double* F, long long ldf) {
+    for (int P = 0; P < ncols; ++P) {
+        const int src = __builtin_amdgcn_readlane(lp, P);
+        if (ln < q.k && ln <= P) F[ln + (size_t)P * ldf] = q.tmp[ln * 65 + src];
+    }
+}
+
+// pseudo_rank (src/enlsip_functions.jl:17-31) of the diagonal in LDS (len <= 64), evaluated by the whole wave.
+__device__ __forceinline__ int wave_pseudo_rank(const double* dg, const int len, const double eps_rank, const int ln) {
+    if (len <= 0) return 0;
+    const double d0 = fabs(dg[0]);
+    if (d0 < eps_rank) return 0;
+    const double tol = d0 * sqrt((double)len) * eps_rank;
+    const bool fail = (ln < len) && !(fabs(dg[ln < len ? ln : 0]) > tol);
+    const unsigned long long mk = __ballot(fail);
+    return mk ? (int)__builtin_ctzll(mk) : len;
+}
+
+}  // namespace gn
