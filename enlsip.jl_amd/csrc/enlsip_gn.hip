@@ -63,7 +63,7 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     P = Plan();
     P.batch = batch; P.m = m; P.n = n; P.t = t;
     P.kA = (int)std::min(n, t);
-    P.RPL = h->tile_rows / 64;
+    P.RPL = (m <= 256 ? 256 : h->tile_rows) / 64;      // a problem of at most 256 rows is one 256-row tile
     P.F = 2 * P.RPL;
     P.ldw = (int)rup(std::max<long long>(m, 1), 32);
     // a leading dimension that is a multiple of 4 KB puts the same row range of every column on the

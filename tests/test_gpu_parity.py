@@ -248,6 +248,35 @@ def test_shape_sweep_register_paths(kind, m, n, t, solver):
         assert rel(out.p, ref.p) <= (1e-6 if kind == "graded" else 1e-9)
 
 
+@pytest.mark.parametrize("kind,m,n,t", [
+    ("full", 50, 20, 30),            # t > n: kA = n, code -1, carried b longer than the F_L11 steps, n2 = 0
+    ("full", 100, 63, 0),            # n2 + 1 = 64: the widest wave-per-problem pivot stage
+    ("full", 100, 64, 0),            # n2 + 1 = 65: falls back to the workgroup pivot stage
+    ("full", 64, 64, 63),            # 63 reflectors of length 64, n2 = 1
+    ("full", 30, 40, 5),             # m < n2: kp = m, columns that never pivot keep LAPACK's swap order
+    ("full", 9, 64, 60),             # tiny m
+    ("full", 200, 33, 33),           # t = n: J2 is empty
+    ("rankdefA", 200, 30, 12),       # code -1, retry with a wider J2
+    ("rankdefA", 40, 12, 20),        # rank-deficient and t > n
+    ("rankdefJ", 256, 32, 4),        # rank-deficient J2 (C5 shape)
+    ("graded", 512, 64, 8),          # graded singular values (C3 shape): norm-downdate recomputations
+])
+def test_small_wave_kernels(kind, m, n, t, solver):
+    """Edge shapes of the one-wave-per-problem stages (k_constraint_small, k_jq1_rows, k_pivot_small, the passenger
+    column of the CAQR factor kernel)."""
+    gen = {"full": synth.make_problem, "rankdefA": synth.make_rank_deficient_A, "rankdefJ": synth.make_rank_deficient_J,
+           "graded": synth.make_graded_J}[kind]
+    J, rx, A, cx = gen(41000 + m + n + t, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    out = solver.solve(J, rx, A, cx)
+    if kind == "full":
+        compare(out, ref, m, n, pivots=(ref.code == 1))
+    else:
+        assert out.rankA == ref.rankA and out.rankJ2 == ref.rankJ2 and out.code == ref.code
+        assert np.array_equal(out.jpvtA, ref.jpvtA)
+        assert rel(out.p, ref.p) <= (1e-5 if kind == "graded" else 1e-9)
+
+
 def test_pipelined_batch_on_caller_stream():
     """Inputs produced on the caller's stream right before the call: the second pipeline half runs on the library's own
     stream and must be ordered after them (event fork in enlsip_gn_solve_batched_dev)."""
