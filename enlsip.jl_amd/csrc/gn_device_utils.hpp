@@ -23,6 +23,15 @@ struct ProbState {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// Orders memory traffic between the LANES OF ONE WAVE: loads that follow may read what other lanes of the wave stored
+// before.  Without it the compiler, which reasons per lane, may hoist a load above another lane's (conditional) store of
+// the same address and forward the stored value only inside the storing lane.  Costs a waitcnt, no barrier instruction.
+__device__ __forceinline__ void wave_mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // one DPP lane permutation of a double (two 32-bit v_mov_dpp)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {

@@ -53,7 +53,9 @@ __global__ __launch_bounds__(64) void k_constraint_small(ConstraintArgs a) {
     if (kA > 0) wave_qrcp<NR, true>(x, q, ln, mypos);
     if (ln < t) jpvtA[mypos] = ln + 1;
     int* lpos = reinterpret_cast<int*>(vbuf);
+    wave_mem_sync();
     if (ln < t) lpos[mypos] = ln;
+    wave_mem_sync();
     const int lp = (ln < t) ? lpos[ln] : 0;          // lane i: the lane (= column of A') that sits at position i
     wave_qrcp_store_upper(q, ln, lp, t, FA, n);
     if (kA > 0) {
@@ -96,13 +98,16 @@ __global__ __launch_bounds__(64) void k_constraint_small(ConstraintArgs a) {
         }
         x[i] = v;
     }
+    wave_mem_sync();          // every lane has taken its column of L11 out of tmp before the second factorisation reuses it
     WaveQrcp ql{};
     ql.rows = t; ql.k = kA; ql.ncand = kA; ql.npart = kA + 1;
     ql.tmp = tmp; ql.vbuf = vbuf; ql.dg = dg; ql.F = FL; ql.ldf = t; ql.tau = tauL;
     int posL = ln, j0 = 0;
     if (kA > 0) j0 = wave_qrcp<NR, false>(x, ql, ln, posL);
     if (ln < kA) jpvtL[posL] = ln + 1;
+    wave_mem_sync();
     if (ln <= kA) lpos[posL] = ln;
+    wave_mem_sync();
     const int lpL = (ln <= kA) ? lpos[ln] : 0;
     wave_qrcp_store_upper(ql, ln, lpL, kA, FL, t);
     if (code == -1) {
@@ -112,6 +117,7 @@ __global__ __launch_bounds__(64) void k_constraint_small(ConstraintArgs a) {
             for (int r = 0; r < NR; ++r)
                 if (j0 + r >= kA && j0 + r < t) tail[j0 + r] = x[r];
         }
+        wave_mem_sync();
         if (ln < t) bvec[ln] = (ln < kA) ? tmp[ln * 65 + kA] : tail[ln];
         // dp1 = U(R_L[1:dimA,1:dimA]) \ b[1:dimA]; p1 = ([dp1; 0][invperm(F_L11.p)])[1:rankA]     (:141-144)
         const int ds = dimA < kA ? dimA : kA;

@@ -14,9 +14,16 @@ namespace gn {
 // LDS (doubles): tmp[kpm * 65] vbuf[64] dg[64] pbuf[nv]
 inline size_t final_small_lds_bytes(int kpm, int nv) { return (size_t)(kpm * 65 + 64 + 64 + nv + 8) * 8; }
 
+#ifdef GN_PS_STAMPS   // timing-only build: phase stamps (100 MHz wall clock) of problem 0 in the last entries of d_out
+#define GN_PS_STAMP(i) do { if (prob == 0 && ln == 0 && a.d_out) stamps[i] = (double)wall_clock64(); } while (0)
+#else
+#define GN_PS_STAMP(i) do { } while (0)
+#endif
+
 template <int NR>
 __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    double stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int prob = blockIdx.x + a.prob0;
     ProbState* stp = a.state + prob;
     const int rankA = stp->rankA, n2 = stp->n2, kp = stp->kp;
@@ -38,16 +45,25 @@ __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
     const int ln = threadIdx.x;
     int status = 0;
 
+    GN_PS_STAMP(0);
     // ---- R0 (upper trapezoid) and z: columns through LDS so that the global loads run along rows ---------------
-    for (int c = 0; c <= n2; ++c) {
-        if (ln < kp) {
-            double v;
-            if (c < n2) v = (ln <= c) ? W[ln + (size_t)(rankA + c) * ldw] : 0.0;
-            else v = W[ln + (size_t)n * ldw];
-            tmp[ln * 65 + c] = v;
+    for (int c0 = 0; c0 <= n2; c0 += 8) {       // eight independent loads in flight, then eight LDS writes
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            v[u] = 0.0;
+            if (ln < kp) {
+                if (c < n2) v[u] = (ln <= c) ? W[ln + (size_t)(rankA + c) * ldw] : 0.0;
+                else if (c == n2) v[u] = W[ln + (size_t)n * ldw];
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (ln < kp && c0 + u <= n2) tmp[ln * 65 + c0 + u] = v[u];
     }
     if (a.zsave && ln < kp) a.zsave[prob * a.sZ + ln] = W[ln + (size_t)n * ldw];
+    wave_mem_sync();
     double x[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) x[r] = (r < kp && ln <= n2) ? tmp[r * 65 + ln] : 0.0;
@@ -55,17 +71,22 @@ __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
     q.rows = kp; q.k = kp; q.ncand = n2; q.npart = n2 + 1;
     q.tmp = tmp; q.vbuf = vbuf; q.dg = dg; q.F = Rt; q.ldf = ldr; q.tau = tauJ;
     int mypos = ln;
+    GN_PS_STAMP(1);
     if (kp > 0) wave_qrcp<NR, false>(x, q, ln, mypos);
+    GN_PS_STAMP(2);
 
     // ---- permutation, upper parts of the columns, rank ---------------------------------------------------------------
     if (ln < n2) jpvtJ[mypos] = ln + 1;
     // lane-of-position table (positions 0..n2): lp of lane i = lane that sits at position i
     int* lpos = reinterpret_cast<int*>(vbuf);
+    wave_mem_sync();
     if (ln <= n2) lpos[mypos] = ln;
+    wave_mem_sync();
     const int lp = (ln <= n2) ? lpos[ln] : 0;
     wave_qrcp_store_upper(q, ln, lp, n2 + 1, Rt, ldr);
     const int rankJ2 = wave_pseudo_rank(dg, kp, a.eps_rank, ln);
     const int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
+    GN_PS_STAMP(3);
 
     // ---- dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]: lane r carries row r of the right-hand side ------------------------
     double zw = (ln < dimJ2 && ln < kp) ? tmp[ln * 65 + n2] : 0.0;
@@ -77,11 +98,15 @@ __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
         if (ln == i) zw = yi;
         if (ln < i) zw -= tmp[ln * 65 + li] * yi;
     }
+    GN_PS_STAMP(4);
     // y = [p1 ; p2],  p2[pJ[i]-1] = (i < dimJ2 ? dp2[i] : 0)
     for (int i = ln; i < rankA; i += WAVE) pbuf[i] = p1[i];
     if (ln < n2) pbuf[rankA + lp] = (ln < dimJ2) ? zw : 0.0;
     // p = F_A.Q * y
+    wave_mem_sync();
     wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);
+    wave_mem_sync();
+    GN_PS_STAMP(5);
     if (a.p_out)
         for (int i = ln; i < n; i += WAVE) a.p_out[prob * a.sPo + i] = pbuf[i];
     if (a.b_out)
@@ -100,6 +125,11 @@ __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
         stp->dimJ2 = dimJ2;
         stp->status |= status;
     }
+#ifdef GN_PS_STAMPS
+    GN_PS_STAMP(6);
+    if (prob == 0 && ln == 0 && a.d_out)
+        for (int i = 0; i < 7; ++i) a.d_out[m - 8 + i] = stamps[i];
+#endif
 }
 
 // Returns false when the launch shape is outside the kernel's range (the caller uses k_pivot_solve).

@@ -31,9 +31,16 @@ struct WaveQrcp {
     double* gcol;
 };
 
+// One pivot step; S = block-relative row of the pivot (the rows shift up by WQ_UNROLL after every block of steps).
+// The pivot lane publishes its RAW column below the diagonal; every lane forms the raw dot product with it — which, in
+// the pivot lane itself, is the squared norm dlarfg needs — and the scale 1 / (alpha - beta) of the Householder vector is
+// folded into the scalars: v = scale * raw, so  v' x = x[S] + scale * (raw' x)  and  x -= (tau v' x) scale * raw.
+// Registers therefore keep raw columns; a processed lane remembers its own scale for the Gram entries.
+constexpr int WQ_UNROLL = 4;
+
 template <int NR, int S, bool GRAM>
 __device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrcp& q, const int j, const int rem, const int ln,
-                                                  int& mypos, double& vn1, double& vn2) {
+                                                  int& mypos, double& vn1, double& vn2, double& myscale) {
     const double tol3z = 1.4901161193847656e-08;  // sqrt(eps), dlaqp2
     // (a) pivot = first position of the largest partial norm among the unprocessed columns
     const bool cand = (ln < q.ncand) && (mypos >= j);
@@ -42,73 +49,52 @@ __device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrc
     // (b) LAPACK's swap of positions j <-> pp
     if (mypos == j) mypos = pp;
     if (ln == pl) mypos = j;
-    // (c) reflector of the pivot column (every lane evaluates its own column; only lane pl's is used)
-    double xn2 = 0.0;
+    // (c) the pivot lane publishes its column below the diagonal (rows beyond the live range are zero)
+    if (ln == pl) {
+#pragma unroll
+        for (int r = S + 1; r < NR; ++r) q.vbuf[r] = x[r];
+    }
+    wave_mem_sync();
+    double v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = (r > S) ? q.vbuf[r] : 0.0;
+    // (d) raw dot products, one short chain per 8 rows
+    double dotraw = 0.0;
 #pragma unroll
     for (int ch = 0; ch < NR / 8; ++ch) {
-        if (8 * ch + 7 > S && 8 * ch < rem) {
+        if (8 * ch + 7 > S) {
+            double pc = 0.0;
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int r = 8 * ch + rr;
-                if (r > S) xn2 += x[r] * x[r];
+                if (r > S) pc += x[r] * v[r];
             }
+            dotraw += pc;
         }
     }
-    const Reflector hme = make_reflector(x[S], xn2);
-    const double beta = wave_bcast(hme.beta, pl), tau = wave_bcast(hme.tau, pl), scale = wave_bcast(hme.scale, pl);
-    if (ln == pl) {
-        x[S] = beta;
-#pragma unroll
-        for (int ch = 0; ch < NR / 8; ++ch) {
-            if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = 8 * ch + rr;
-                    if (r > S) {
-                        x[r] *= scale;
-                        q.vbuf[r] = x[r];
-                    }
-                }
-            }
-        }
-    }
-    // (d) apply H_j to the unprocessed columns and the right-hand sides
+    const Reflector h = make_reflector(wave_bcast(x[S], pl), wave_bcast(dotraw, pl));    // uniform
+    const double tau = h.tau, scale = h.scale;
     const bool upd = (mypos > j) && (ln < q.npart);
-    const bool gram = GRAM && (mypos < j) && (ln < q.npart);
-    if (upd || gram) {
-        double dot = x[S];
+    const double dot = x[S] + scale * dotraw;          // v' x
+    if (GRAM && (mypos < j) && (ln < q.npart)) q.gcol[mypos] = myscale * dot;   // G[l][j] = v_l' v_j, l = this lane's position
+    if (ln == pl) {
+        x[S] = h.beta;
+        myscale = scale;
+    }
+    if (upd && tau != 0.0) {
+        const double wd = tau * dot;
+        const double ws = wd * scale;
+        x[S] -= wd;
 #pragma unroll
-        for (int ch = 0; ch < NR / 8; ++ch) {
-            if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = 8 * ch + rr;
-                    if (r > S) dot += x[r] * q.vbuf[r];
-                }
-            }
-        }
-        if (upd && tau != 0.0) {
-            const double wd = tau * dot;
-            x[S] -= wd;
-#pragma unroll
-            for (int ch = 0; ch < NR / 8; ++ch) {
-                if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) {
-                        const int r = 8 * ch + rr;
-                        if (r > S) x[r] -= wd * q.vbuf[r];
-                    }
-                }
-            }
-        }
-        if (gram) q.gcol[mypos] = dot;       // G[l][j] = v_l' v_j, l = position of this lane's column
+        for (int r = S + 1; r < NR; ++r) x[r] -= ws * v[r];
     }
     if constexpr (GRAM) {
+        wave_mem_sync();      // gcol is complete
         // T[0:j, j] = -tau_j T[0:j, 0:j] G[0:j, j]; T[j][j] = tau_j   (lane l builds row l)
         if (ln < j) {
-            double s = 0.0;
-            for (int i = ln; i < j; ++i) s += q.Tl[ln + 64 * i] * q.gcol[i];
-            q.Tl[ln + 64 * j] = -tau * s;
+            double sacc = 0.0;
+            for (int i = ln; i < j; ++i) sacc += q.Tl[ln + 64 * i] * q.gcol[i];
+            q.Tl[ln + 64 * j] = -tau * sacc;
         }
         if (ln == j) q.Tl[j + 64 * j] = tau;
     }
@@ -116,9 +102,10 @@ __device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrc
     if (mypos >= j && ln < q.npart) q.tmp[j * 65 + ln] = x[S];
     if (ln == 0) {
         q.tau[j] = tau;
-        q.dg[j] = beta;
+        q.dg[j] = h.beta;
     }
-    if (j + 1 + ln < q.rows) q.F[(size_t)j * q.ldf + j + 1 + ln] = q.vbuf[S + 1 + ln];   // row j+1+ln <- block row S+1+ln
+    if (j + 1 + ln < q.rows) q.F[(size_t)j * q.ldf + j + 1 + ln] = q.vbuf[S + 1 + ln] * scale;   // row j+1+ln <- block row S+1+ln
+    wave_mem_sync();          // every reader of vbuf is done before the next publish
     // (f) dlaqp2 norm downdate, lane-local
     if (upd && ln < q.ncand && vn1 != 0.0) {
         const double ajc = x[S];
@@ -129,15 +116,7 @@ __device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrc
         if (temp2 <= tol3z) {
             double s2 = 0.0;
 #pragma unroll
-            for (int ch = 0; ch < NR / 8; ++ch) {
-                if (8 * ch + 7 > S && 8 * ch < rem) {
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) {
-                        const int r = 8 * ch + rr;
-                        if (r > S) s2 += x[r] * x[r];
-                    }
-                }
-            }
+            for (int r = S + 1; r < NR; ++r) s2 += x[r] * x[r];
             const double nv = (j + 1 < q.rows) ? sqrt(s2) : 0.0;
             vn1 = nv;
             vn2 = nv;
@@ -156,22 +135,27 @@ __device__ __forceinline__ int wave_qrcp(double (&x)[NR], const WaveQrcp& q, con
     {
         double s = 0.0;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) s += x[r] * x[r];
+        for (int ch = 0; ch < NR / 8; ++ch) {
+            double pc = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) pc += x[8 * ch + rr] * x[8 * ch + rr];
+            s += pc;
+        }
         vn1 = sqrt(s);
     }
-    double vn2 = vn1;
+    double vn2 = vn1, myscale = 0.0;
     mypos = ln;
     int j0 = 0;
     for (;;) {
         const int rem = q.rows - j0;
 #define GN_WQ_STEP(S) \
-    if (j0 + S < q.k) wave_qrcp_substep<NR, S, GRAM>(x, q, j0 + S, rem, ln, mypos, vn1, vn2);
-        GN_WQ_STEP(0) GN_WQ_STEP(1) GN_WQ_STEP(2) GN_WQ_STEP(3) GN_WQ_STEP(4) GN_WQ_STEP(5) GN_WQ_STEP(6) GN_WQ_STEP(7)
+    if (j0 + S < q.k) wave_qrcp_substep<NR, S, GRAM>(x, q, j0 + S, rem, ln, mypos, vn1, vn2, myscale);
+        GN_WQ_STEP(0) GN_WQ_STEP(1) GN_WQ_STEP(2) GN_WQ_STEP(3)
 #undef GN_WQ_STEP
-        if (j0 + 8 >= q.k) break;
+        if (j0 + WQ_UNROLL >= q.k) break;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) x[r] = (r + 8 < NR) ? x[(r + 8 < NR) ? r + 8 : r] : 0.0;
-        j0 += 8;
+        for (int r = 0; r < NR; ++r) x[r] = (r + WQ_UNROLL < NR) ? x[(r + WQ_UNROLL < NR) ? r + WQ_UNROLL : r] : 0.0;
+        j0 += WQ_UNROLL;
     }
     return j0;
 }
@@ -180,6 +164,7 @@ __device__ __forceinline__ int wave_qrcp(double (&x)[NR], const WaveQrcp& q, con
 // lp: lane i holds the lane that sits at position i.  ncols: positions written.
 __device__ __forceinline__ void wave_qrcp_store_upper(const WaveQrcp& q, const int ln, const int lp, const int ncols,
                                                       double* F, long long ldf) {
+    wave_mem_sync();
     for (int P = 0; P < ncols; ++P) {
         const int src = __builtin_amdgcn_readlane(lp, P);
         if (ln < q.k && ln <= P) F[ln + (size_t)P * ldf] = q.tmp[ln * 65 + src];
