@@ -529,7 +529,9 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
             const int kp_launch = (int)std::min<long long>(m, n2_launch);
             if ((size_t)kp_launch * (n2_launch + 1) > (size_t)CMAT_DOUBLES) {
                 if (h->qrcp_mode == 2) {
-                    rc = run_qrcp_block(h, n2_launch);
+                    // more than 512 rows do not fit the register form of the blocked factorisation; its LDS-slab form
+                    // (16 candidates, ~13 steps per block, 14 us per step) loses to one launch per pivot step (6.5 us)
+                    rc = (kp_launch > 512 && !getenv("ENLSIP_GN_SB_LDS")) ? run_qrcp_dist(h, n2_launch) : run_qrcp_block(h, n2_launch);
                     if (rc) return rc;
                 } else {
                     rc = (h->qrcp_mode == 0) ? run_qrcp_persist(h, n2_launch) : -1;

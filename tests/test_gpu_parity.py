@@ -232,6 +232,8 @@ def test_pipelined_device_batch_matches_oracle(solver):
     ("graded", 1200, 280, 30),       # graded singular values: norm-downdate recomputations
     ("full", 300, 330, 40),          # m < n2: kp = m
     ("full", 513, 140, 0),           # no constraints, one row past a tile boundary
+    ("full", 1300, 600, 8),          # kp = 592 > 512 rows: launch-per-step pivoted QR (k_qd_*)
+    ("rankdefJ", 1100, 560, 6),      # the same path with a rank-deficient J2
 ])
 def test_shape_sweep_register_paths(kind, m, n, t, solver):
     """Shapes chosen to run the register-resident factorisations (k_geqp3_reg, k_sb_factor_reg), the gathered block
