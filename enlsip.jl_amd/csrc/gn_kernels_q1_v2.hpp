@@ -24,6 +24,17 @@
 #include "gn_kernels_q1.hpp"
 #include "gn_kernels_update_v4.hpp"
 
+#ifndef ENLSIP_JQ1_ABLATE
+#define ENLSIP_JQ1_ABLATE 0     // timing-only ablations for tests/microbench/jq1_bench.hip: 1 = no MFMAs, 2 = no J loads / W stores,
+#endif                          // 3 = no V staging (wrong results in every non-zero mode)
+
+#ifdef ENLSIP_JQ1_STAMPS        // harness only: phase stamps (100 MHz) of a few sample workgroups
+__device__ long long g_jq1_stamps[8 * 8];
+#define JQ1_STAMP(i) do { if (blockIdx.x == 37 && (blockIdx.y & 31) == 3 && blockIdx.y < 256 && threadIdx.x == 0) g_jq1_stamps[(blockIdx.y >> 5) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define JQ1_STAMP(i) do { } while (0)
+#endif
+
 namespace gn {
 
 constexpr int Q2_LDV = 18;                   // V image: [reflector][16 tile columns], conflict-free as B and as A operand
@@ -55,6 +66,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
     const int lr = ln & 15, lq = ln >> 4;
     double* Vs = ush + w * Q2_VS;
 
+    JQ1_STAMP(0);
     // ---- J tiles -> registers (shape restrictions of launch_jq1_v2: every tile and every row pair exists) -------
     // addresses = wave-uniform base + one 32-bit lane offset (saddr + voffset form, no 64-bit address registers)
     const unsigned jlane = (unsigned)(((size_t)lq * a.ldj + NP * lr) * 8);     // row (pair) NP lr, column lq of a 4-column step
@@ -66,7 +78,9 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         for (int r = 0; r < 4; ++r)
         {
             const char* src = (const char*)(Jin + (size_t)(16 * (w + Q2_NW * T) + 4 * r) * a.ldj + row0) + jlane;
-            if (NP == 2) {
+            if (ENLSIP_JQ1_ABLATE == 2) {
+                jt[T][r][0] = (double)tid; jt[T][r][NP - 1] = 1.0;
+            } else if (NP == 2) {
                 const v4_d2 x = __builtin_nontemporal_load((const v4_d2*)src);     // J is streamed once
                 jt[T][r][0] = x[0];
                 jt[T][r][NP - 1] = x[1];
@@ -82,10 +96,12 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         const int rp = ln & 7, jc = ln >> 3;
         const unsigned vlane = (unsigned)(((size_t)jc * n + 2 * rp) * 8);
         auto fetch_v = [&](int tile, v4_d2 (&x)[8]) {
+            if (ENLSIP_JQ1_ABLATE == 3) return;
 #pragma unroll
             for (int q = 0; q < 8; ++q) x[q] = *(const v4_d2*)((const char*)(FA + (size_t)(c0 + 8 * q) * n + 16 * tile) + vlane);
         };
         auto put_v = [&](int tile, const v4_d2 (&x)[8]) {
+            if (ENLSIP_JQ1_ABLATE == 3) return;
             const int gr = 16 * tile + 2 * rp;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -101,6 +117,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
             return T < NTW && 16 * tile + 15 >= c0;
         };
         // ---- phase 1: per-wave partial W1 = J V_b over the wave's tiles --------------------------------
+        JQ1_STAMP(1);
         mfma_d4 acc[NP][4];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -125,7 +142,8 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
                         for (int p = 0; p < NP; ++p) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                acc[p][jg] = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[T][r][p], bv[r], acc[p][jg], 0, 0, 0);
+                                if (ENLSIP_JQ1_ABLATE == 1) acc[p][jg][r] += jt[T][r][p] + bv[r];
+                                else acc[p][jg] = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[T][r][p], bv[r], acc[p][jg], 0, 0, 0);
                             __builtin_amdgcn_sched_barrier(0);     // keep the chain of 4 on one accumulator together
                         }
                     }
@@ -137,7 +155,9 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         }
         // ---- phase 2: W1 = sum over waves (slots of waves 4..7, then += waves 0..3), W2 = -W1 T_b ------------
         // partial layout: lane-linear, index ((p * 4 + jg) * 4 + r) * 64 + ln
+        JQ1_STAMP(2);
         __syncthreads();                                   // every wave is done with its V image
+        JQ1_STAMP(3);
         {
             double* ps = ush + (w % NS) * Q2_PS;
             if (w >= NS) {
@@ -184,6 +204,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
             for (int r = 0; r < 4; ++r) W2s[(16 * jg2 + lr) * Q2_LDW + 16 * p2 + lq + 4 * r] = -t2[r];
         }
         __syncthreads();
+        JQ1_STAMP(4);
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 3: tile^T += V_b W2^T  (D^T[i = column lq + 4 r][j = row pair lr]) -------------------------
         {
@@ -213,7 +234,8 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
                         for (int p = 0; p < NP; ++p) {
 #pragma unroll
                             for (int k4 = 0; k4 < 4; ++k4)
-                                fr[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4], bw[p][k4], fr[p], 0, 0, 0);
+                                if (ENLSIP_JQ1_ABLATE == 1) fr[p][k4] += av[k4] + bw[p][k4];
+                                else fr[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4], bw[p][k4], fr[p], 0, 0, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -227,6 +249,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        JQ1_STAMP(5);
         __syncthreads();      // W2s and the V images are rewritten by the next block
     }
 
@@ -243,7 +266,8 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) dp[p] += jt[T][r][p] * pc;
             char* dst = (char*)(W + (size_t)(16 * (w + Q2_NW * T) + 4 * r) * ldw + row0) + wlane;   // W 256-byte aligned
-            if (NP == 2) __builtin_nontemporal_store((v4_d2){jt[T][r][0], jt[T][r][NP - 1]}, (v4_d2*)dst);
+            if (ENLSIP_JQ1_ABLATE == 2) { if (jt[T][r][0] == 1.2345) *(double*)dst = 0.0; }
+            else if (NP == 2) __builtin_nontemporal_store((v4_d2){jt[T][r][0], jt[T][r][NP - 1]}, (v4_d2*)dst);
             else *(double*)dst = jt[T][r][0];
         }
 #pragma unroll
@@ -260,6 +284,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         for (int q = 0; q < Q2_NW; ++q) s += dred[q][tid];
         W[row + (size_t)n * ldw] = -s - rx[row];
     }
+    JQ1_STAMP(6);
 }
 
 // The second form is the straight-line fast path for regular shapes: n a multiple of 128 (<= 512), m a multiple of
