@@ -49,6 +49,12 @@ typedef double v4_d2 __attribute__((ext_vector_type(2)));
 #endif
 // timing experiments only (results wrong when != 0): 2 no V loads, 3 no C traffic, 4 no MFMA, 5 MFMA only
 constexpr int V4_ABLATE = ENLSIP_V4_ABLATE;
+#ifdef ENLSIP_V4_STAMPS         // harness only (tests/microbench/update_bench.hip): phase stamps (100 MHz) of sample workgroups
+__device__ long long g_v4_stamps[8 * 8];
+#define V4_STAMP(i) do { if (blockIdx.x == 3 && blockIdx.y == 5 && (blockIdx.z & 31) == 7 && blockIdx.z < 256 && threadIdx.x == 0) g_v4_stamps[(blockIdx.z >> 5) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define V4_STAMP(i) do { } while (0)
+#endif
 
 constexpr int V4_LD = 34;                    // leading dimension of the per-wave transpose images
 constexpr int V4_IMG = PB * V4_LD;           // doubles per image (C or V), 32 columns
@@ -164,6 +170,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     };
 
     // ---- product 1: per-wave partial W1 = V' C ------------------------------------------------------------
+    V4_STAMP(0);
     v4_d4 acc[2][2];
 #pragma unroll
     for (int it = 0; it < 2; ++it)
@@ -228,6 +235,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    V4_STAMP(1);
     v4_d2 vb[2][4];                                      // ring over (unit, half)
     if (NGW > 0) issue_v(0, 0, vb[0]);                   // travels during the reduction step
 
@@ -238,7 +246,9 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) stage[w][(16 * it + lq + 4 * r) * PB + 16 * ct + lr] = acc[it][ct][r];
+    V4_STAMP(2);
     __syncthreads();
+    V4_STAMP(3);
     {
         v4_d4 t = (v4_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -253,6 +263,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         for (int r = 0; r < 4; ++r) W2l[(16 * it2 + lq + 4 * r) * PB + ((16 * ct2 + lr) ^ (16 * (lq & 1)))] = -t[r];   // swizzled, see the read
     }
     __syncthreads();
+    V4_STAMP(4);
 
     // ---- product 2: D^T[col][row pair] += W2^T V^T, even and odd rows of each unit, stored at once ----------
 #pragma unroll
@@ -308,6 +319,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             }
         __builtin_amdgcn_sched_barrier(0);
     }
+    V4_STAMP(5);
 }
 
 template <int RPL, bool TRI, bool CFULL, int NCT, bool RMASK = false, class Post = V4NoPost, bool GATHER = false>
@@ -323,11 +335,15 @@ __device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, doub
     else v4_body<RPL, TRI, CFULL, 0, NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
 }
 
+#ifndef ENLSIP_V4_CW
+#define ENLSIP_V4_CW 32          // columns per workgroup (experiment: 16 with 3 workgroups per CU)
+#endif
 template <int RPL, bool TRI>
-__global__ __launch_bounds__(256, 2) void k_caqr_update_v4(CaqrArgs a) {
+__global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update_v4(CaqrArgs a) {
     __shared__ __attribute__((aligned(16))) double stage[4][V4_STAGE];   // per-wave transpose images / W1 partials
     __shared__ __attribute__((aligned(16))) double W2l[PB * PB];         // W2 = -T' W1   [k][j]
 
+    V4_STAMP(6);
     const int prob = blockIdx.z + a.prob0;
     const ProbState st = a.state[prob];
     const int r0 = a.panel * PB;
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4(CaqrArgs a) {
     const int g = blockIdx.x;
     const int first = r0 + c.bw;
     const int ncols = st.n2 + 1 - first;
-    c.cb0 = blockIdx.y * 32;
+    c.cb0 = blockIdx.y * ENLSIP_V4_CW;
     if (c.cb0 >= ncols) return;
     c.rows_valid = 0;
     c.dshift = 0;
@@ -361,13 +377,16 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4(CaqrArgs a) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) cmask |= (c.cb0 + 16 * (b >> 2) + 4 * (b & 3) + lq < ncols) ? (1u << b) : 0u;
     }
-    if (cfull) v4_dispatch<RPL, TRI, true, 2>(c, w, ngw, stage, W2l);
+    if (ENLSIP_V4_CW == 16) {
+        if ((ncols - c.cb0 >= 16) && (c.bw == PB)) v4_dispatch<RPL, TRI, true, 1>(c, w, ngw, stage, W2l);
+        else v4_dispatch<RPL, TRI, false, 1>(c, w, ngw, stage, W2l, cmask, cmask);
+    } else if (cfull) v4_dispatch<RPL, TRI, true, 2>(c, w, ngw, stage, W2l);
     else if (ncols - c.cb0 <= 16) v4_dispatch<RPL, TRI, false, 1>(c, w, ngw, stage, W2l, cmask, cmask);
     else v4_dispatch<RPL, TRI, false, 2>(c, w, ngw, stage, W2l, cmask, cmask);
 }
 
 inline void launch_update_v4(int RPL, const CaqrArgs& a, int groups, int ncols, int batch, hipStream_t s) {
-    dim3 grid(groups, (ncols + 31) / 32, batch);
+    dim3 grid(groups, (ncols + ENLSIP_V4_CW - 1) / ENLSIP_V4_CW, batch);
     if (a.level == 0) {
         if (RPL == 8) hipLaunchKernelGGL((k_caqr_update_v4<8, false>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_caqr_update_v4<4, false>), grid, dim3(256), 0, s, a);

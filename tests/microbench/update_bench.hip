@@ -3,7 +3,8 @@
 // of gn_kernels_caqr.hpp is timed beside it.  The check recomputes C - V (T' (V' C)) in plain host loops
 // for sampled columns of problem 0.
 // Build: hipcc --offload-arch=gfx950 -O3 -w -std=c++17 -I enlsip.jl_amd/csrc -o tests/microbench/update_bench tests/microbench/update_bench.hip
-//        (-DENLSIP_V4_ABLATE=2|3|4|5 for the timing-only ablations documented in the kernel header)
+//        (-DENLSIP_V4_ABLATE=2|3|4|5 for the timing-only ablations documented in the kernel header, -DENLSIP_V4_STAMPS for
+//        per-phase wall-clock stamps of sample workgroups; the stamps themselves cost ~25 %)
 // Run  : update_bench [batch=256] [panel=0] [level=0]
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -116,5 +117,13 @@ int main(int argc, char** argv) {
         printf("%s: %.3f ms / launch   %.0f GB/s algorithmic   (%.2f us per workgroup-slot)\n", which ? "v4  " : "refl", ms, bytes / ms * 1e-6,
                ms * 1e3 / ((double)groups * ((ntrail + 31) / 32) * batch / 256.0));
     }
+#ifdef ENLSIP_V4_STAMPS
+    long long st[64];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_v4_stamps), sizeof(st)));
+    for (int g = 0; g < 8; ++g)
+        printf("wg (3, 5, %3d): setup %5.2f us | product1 (C, V loads + MFMA) %5.2f | partial->LDS %5.2f | barrier %5.2f | T-MFMA + barrier %5.2f | product2 + stores %5.2f | total %5.2f\n",
+               32 * g + 7, (st[g*8+0]-st[g*8+6])*0.01, (st[g*8+1]-st[g*8+0])*0.01, (st[g*8+2]-st[g*8+1])*0.01, (st[g*8+3]-st[g*8+2])*0.01,
+               (st[g*8+4]-st[g*8+3])*0.01, (st[g*8+5]-st[g*8+4])*0.01, (st[g*8+5]-st[g*8+6])*0.01);
+#endif
     return 0;
 }
