@@ -185,7 +185,7 @@ def main() -> int:
                     roofline["traffic_source"] = "profiles/r1e_update_traffic_pmc.json"
 
     cpu = None
-    if rank == 0 and args.cpu_budget > 0:
+    if rank == 0 and world == 1 and args.cpu_budget > 0:      # the CPU leg runs at N = 1 only
         from oracle import cpu_baseline as cb      # measurement leg only
         Jh = np.asfortranarray(J[0].cpu().numpy().T)
         sps, nsolves, secs, threads = cb.time_baseline(Jh, rx[0].cpu().numpy(), A0, c0, budget_s=args.cpu_budget)
