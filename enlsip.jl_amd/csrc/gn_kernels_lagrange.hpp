@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_gemv_n_add(const double* __restrict__ A
                                                     double* __restrict__ y) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
-    double s = x0[r];
+    double s = x0 ? x0[r] : 0.0;
     for (int c = 0; c < ncols; ++c) s += A[r + (size_t)c * ld] * p[c];
     y[r] = s;
 }

@@ -223,4 +223,12 @@ function gradient_hip(h::Handle, n::Integer)
     return g
 end
 
+"""    jacobian_times_hip(h, p, m, t) -> (J*p, C.A*p) on the J and A of the last solve (src/enlsip_functions.jl:2226-2229)"""
+function jacobian_times_hip(h::Handle, p::Vector{Float64}, m::Integer, t::Integer)
+    Jp = zeros(Float64, m); Ap = zeros(Float64, t)
+    GC.@preserve p Jp Ap check(h, ccall((:enlsip_gn_jacobian_times, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h.ptr, 0, p, Jp, t > 0 ? pointer(Ap) : Ptr{Float64}(C_NULL)))
+    return Jp, Ap
+end
+
 end # module

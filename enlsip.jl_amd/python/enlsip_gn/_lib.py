@@ -59,6 +59,7 @@ PROTOTYPES = {
     "enlsip_gn_get_JQ1": (C.c_int, [_h, _i64, C.c_void_p, _i64]),
     "enlsip_gn_resolve": (C.c_int, [_h, _i64, _i64, _i64, _i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "enlsip_gn_gradient": (C.c_int, [_h, _i64, C.c_void_p]),
+    "enlsip_gn_jacobian_times": (C.c_int, [_h, _i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "enlsip_gn_first_lagrange": (C.c_int, [_h, _i64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                            C.POINTER(C.c_double)]),
     "enlsip_gn_second_lagrange": (C.c_int, [_h, _i64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),

@@ -195,6 +195,13 @@ class GNSolver:
         self._chk(self._lib.enlsip_gn_gradient(self._h, prob, _fptr(g)))
         return g
 
+    def jacobian_times(self, m: int, t: int, p: np.ndarray, prob: int = 0):
+        """(J p, A_active p) of the last solve's J and A (src/enlsip_functions.jl:2226-2229)."""
+        pv = np.ascontiguousarray(p, dtype=np.float64)
+        Jp, Ap = np.zeros(m), np.zeros(t)
+        self._chk(self._lib.enlsip_gn_jacobian_times(self._h, prob, _fptr(pv), _fptr(Jp), _fptr(Ap) if t else None))
+        return Jp, Ap
+
     def first_lagrange(self, t: int, grad_fx: Optional[np.ndarray] = None, diag_scale: Optional[np.ndarray] = None,
                        eps_rank: float = SQRT_EPS, prob: int = 0):
         """first_lagrange_mult_estimate!: returns (lambda, grad_res)."""

@@ -160,8 +160,13 @@ int enlsip_gn_resolve(enlsip_gn_handle h, int64_t prob, int64_t dimA, int64_t di
  *                             b = J1' (rx + J p_gn) with the resident J1 = (J*F_A.Q)[:, 1:t] (the reference
  *                             recomputes J*F_A.Q here, :526).  Returns -7 if the pseudo-rank under eps_rank
  *                             exceeds the rank the solve used (those J1 columns were factored in place).
+ * enlsip_gn_jacobian_times    Jp = J * p (m) and Ap = C.A * p (t, active rows), the products the line search sets up
+ *                             with (src/enlsip_functions.jl:2226-2229: `Jp = J * p`, `active_Ap = (active_constraint.A) * p`),
+ *                             on the J and A' of the last solve; either output may be NULL.  (The product with the FULL
+ *                             constraint Jacobian, :2227, involves rows the library never sees and stays on the host.)
  */
 int enlsip_gn_gradient(enlsip_gn_handle h, int64_t prob, double* grad);
+int enlsip_gn_jacobian_times(enlsip_gn_handle h, int64_t prob, const double* p, double* Jp, double* Ap);
 int enlsip_gn_first_lagrange(enlsip_gn_handle h, int64_t prob, const double* grad_fx, const double* diag_scale,
                              double eps_rank, double* lambda, double* grad_res);
 int enlsip_gn_second_lagrange(enlsip_gn_handle h, int64_t prob, const double* p_gn, const double* diag_scale,

@@ -339,6 +339,9 @@ def test_multiplier_estimates_on_device(kind, m, n, t, scaling, solver):
     lam2_ref = go.second_lagrange_mult_estimate(J, ref.F_A, rx, ref.p, t, scaling, diag_scale)
     lam2 = solver.second_lagrange(t, out.p, diag_scale if scaling else None)
     assert rel(lam2, lam2_ref) <= 1e-9
+    Jp, Ap = solver.jacobian_times(m, t, out.p)          # line-search products (:2226-2229) on the resident J, A
+    assert rel(Jp, J @ out.p) <= 1e-13
+    assert np.abs(Ap - A @ out.p).max() <= 1e-13 * max(1.0, np.abs(A @ out.p).max())
 
 
 def test_argument_errors(solver):
