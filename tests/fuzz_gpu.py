@@ -1,0 +1,68 @@
+"""Randomised shape sweep of the HIP path against the oracle (diagnostic; the regular suite holds the fixed cases).
+usage: python3 tests/fuzz_gpu.py [cases=120] [seed=1]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "enlsip.jl_amd", "python")); sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import gn_oracle as go, synth
+from enlsip_gn import GNSolver
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / (nb if nb > 0 else 1.0))
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    s = GNSolver(device=0)
+    bad = 0
+    t0 = time.time()
+    for k in range(cases):
+        cls = rng.integers(0, 5)
+        if cls == 0:      # tiny
+            n = int(rng.integers(1, 12)); m = int(rng.integers(1, 30)); t = int(rng.integers(0, n + 3))
+        elif cls == 1:    # small wave kernels
+            n = int(rng.integers(8, 65)); m = int(rng.integers(n // 2 + 1, 700)); t = int(rng.integers(0, min(n, 63) + 1))
+        elif cls == 2:    # mid
+            n = int(rng.integers(65, 300)); m = int(rng.integers(n, 2500)); t = int(rng.integers(0, min(n, 80)))
+        elif cls == 3:    # register paths / wide
+            n = int(rng.integers(300, 640)); m = int(rng.integers(200, 1800)); t = int(rng.integers(0, 70))
+        else:             # m < n
+            n = int(rng.integers(20, 200)); m = int(rng.integers(1, n)); t = int(rng.integers(0, min(n, 40)))
+        kind = ["full", "full", "full", "rankdefA", "rankdefJ", "graded"][int(rng.integers(0, 6))]
+        if kind == "rankdefA" and t < 2: kind = "full"
+        if kind in ("rankdefJ", "graded") and (n - t < 3 or m < 4): kind = "full"
+        gen = {"full": synth.make_problem, "rankdefA": synth.make_rank_deficient_A, "rankdefJ": synth.make_rank_deficient_J,
+               "graded": synth.make_graded_J}[kind]
+        try:
+            J, rx, A, cx = gen(90000 + k, m, n, t)
+            ref = go.gn_subproblem(J, rx, A, cx)
+        except Exception as e:          # generator / oracle limits, not ours
+            print(f"skip {kind} m={m} n={n} t={t}: {type(e).__name__}")
+            continue
+        out = s.solve(J, rx, A, cx)
+        tol = 1e-5 if kind == "graded" else (1e-8 if kind != "full" else 1e-10)
+        ok = (out.rankA, out.code) == (ref.rankA, ref.code) and np.all(np.isfinite(out.p))
+        if kind != "graded":
+            ok = ok and out.rankJ2 == ref.rankJ2
+        if kind == "rankdefA" and m < n - ref.rankA:
+            # Q1's null-space columns are rounding-determined for a rank-deficient A, and an underdetermined J2 (m < n2) takes a
+            # BASIC solution in that basis: p itself is not unique across implementations, its residuals are
+            rj, ra = np.linalg.norm(J @ out.p + rx), np.linalg.norm(A @ out.p + cx)
+            rj0, ra0 = np.linalg.norm(J @ ref.p + rx), np.linalg.norm(A @ ref.p + cx)
+            ok = ok and abs(rj - rj0) <= 1e-8 * max(1.0, rj0) and abs(ra - ra0) <= 1e-8 * max(1.0, ra0)
+        else:
+            ok = ok and rel(out.p, ref.p) <= tol
+        if not ok:
+            bad += 1
+            print(f"FAIL {kind} m={m} n={n} t={t}: ranks hip ({out.rankA},{out.rankJ2},{out.code}) ref ({ref.rankA},{ref.rankJ2},{ref.code}) "
+                  f"rel p {rel(out.p, ref.p):.2e}")
+    print(f"{cases} cases, {bad} failures, {time.time() - t0:.1f} s")
+    s.close()
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
