@@ -505,6 +505,8 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         qa.FA = h->FA; qa.sFA = P.sFA; qa.TA = h->TA; qa.sTA = P.sTA; qa.p1 = h->p1; qa.sP1 = P.sP1;
         qa.W = h->W; qa.sW = P.sW; qa.state = h->state;
         qa.prob0 = 0;
+        // V T' of the fast path lives in the (still unused) working matrix of the pivoted QR
+        qa.VT = (P.sM >= (long long)n * KBLK) ? h->qdM : nullptr; qa.sVT = P.sM;
         if (h->flags & ENLSIP_GN_UPDATE_REFLECTORS) launch_jq1(qa, (int)batch, s);   // plain-FMA A/B partner
         else if (launch_jq1_rows(qa, (int)batch, s)) {}                             // small n, few reflectors
         else if (getenv("ENLSIP_GN_JQ1_V1") || !launch_jq1_v2(qa, (int)batch, s)) launch_jq1_mfma(qa, (int)batch, s);

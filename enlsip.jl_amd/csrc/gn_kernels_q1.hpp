@@ -23,6 +23,7 @@ struct JQ1Args {
     double* W;         long long sW;      // ldw x (n + 1)
     const ProbState* state;
     int prob0;
+    double* VT;        long long sVT;     // k_jq1_v2 only: V T' of the (single) reflector block, n x 64 (ld n), built by k_vt
 };
 
 // LDS (doubles): Jl[RB * n] Vl[KC * 65] Wv[RB * 64] Wt[RB * 64] red[256]

@@ -15,7 +15,9 @@
 //    image [reflector][16] (ld 18), read as B operand of product 1 and as A operand of product 3: no workgroup
 //    barrier in either product;
 //  * the only workgroup-wide step is the reduction of W1 over the waves (through 32 KB of LDS that alias
-//    the V images) fused with W2 = -W1 T on the matrix pipe.
+//    the V images).  T is applied to V once per problem instead (k_vt: Vt = V T', 4 MFLOP), so that
+//    J -= (J V) Vt' needs no second small product between the two big ones: that step used to cost 11 of the
+//    53 us of a workgroup (T from L2, 2 x 16 dependent MFMAs behind three barriers).
 // Work per workgroup: 2 x 1024 + 128 MFMAs for 32 rows, i.e. the kernel is bound by the FP64 matrix pipe
 // (4 m n t flop: 1.96 ms for the C2 batch of 256 at the 70 TF/s the pipe sustains; measured 3.9 ms).
 // The body must stay free of runtime loops around the tile code: loop-invariant code motion otherwise hoists every
@@ -40,6 +42,30 @@ namespace gn {
 constexpr int Q2_LDV = 18;                   // V image: [reflector][16 tile columns], conflict-free as B and as A operand
 constexpr int Q2_VS = KBLK * Q2_LDV;         // doubles per wave image
 
+// Vt = V T' for one reflector block (kA = 64): Vt[c][k] = sum_{j = k}^{min(c, 63)} V[c][j] T[k][j], V the unit lower
+// trapezoid held in FA, T upper triangular.  One thread per (row c, reflector k); T through LDS.
+__global__ __launch_bounds__(256) void k_vt(JQ1Args a) {
+    __shared__ double Ts[KBLK * (KBLK + 1)];
+    const int n = a.n;
+    const int prob = blockIdx.y + a.prob0;
+    const double* FA = a.FA + prob * a.sFA;
+    const double* TA = a.TA + prob * a.sTA;
+    double* VT = a.VT + prob * a.sVT;
+    for (int e = threadIdx.x; e < KBLK * KBLK; e += 256) Ts[(e & 63) * (KBLK + 1) + (e >> 6)] = TA[e];   // Ts[k][j] = T[k][j]
+    __syncthreads();
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c >= n) return;
+    for (int k = threadIdx.x >> 6; k < KBLK; k += 4) {
+        double s = 0.0;
+        const int jmax = c < KBLK - 1 ? c : KBLK - 1;
+        for (int j = k; j <= jmax; ++j) {
+            const double v = (c > j) ? FA[c + (size_t)j * n] : 1.0;       // j == c: unit diagonal
+            s += v * Ts[k * (KBLK + 1) + j];
+        }
+        VT[c + (size_t)k * n] = s;
+    }
+}
+
 template <int NTW, int Q2_NW, int NP>     // NTW tiles per wave, Q2_NW waves: n = 16 * NTW * Q2_NW; NP row fragments: 16 NP rows
 __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
     constexpr int Q2_RB = 16 * NP;
@@ -57,7 +83,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
     const double* Jin = a.J + prob * a.strideJ;
     const double* rx = a.rx + prob * a.stride_rx;
     const double* FA = a.FA + prob * a.sFA;
-    const double* TA = a.TA + prob * a.sTA;
+    const double* VT = a.VT + prob * a.sVT;
     const double* p1 = a.p1 + prob * a.sP1;
     double* W = a.W + prob * a.sW;
     const int rankA = a.state[prob].rankA;
@@ -71,6 +97,17 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
     // addresses = wave-uniform base + one 32-bit lane offset (saddr + voffset form, no 64-bit address registers)
     const unsigned jlane = (unsigned)(((size_t)lq * a.ldj + NP * lr) * 8);     // row (pair) NP lr, column lq of a 4-column step
     const unsigned wlane = (unsigned)(((size_t)lq * ldw + NP * lr) * 8);
+    // p1 entries of the wave's first tile (columns < kA = 64 live in tiles 0..3 = T 0 of every wave) and the rx entry of the
+    // final row: fetched here so that the epilogue has no load queued behind its own stores (loads and stores retire in
+    // order under vmcnt: a load after 32 tile stores waits for their HBM acknowledgements)
+    static_assert(16 * Q2_NW >= KBLK, "p1 columns must lie in the first tile of every wave");
+    double pcv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = 16 * w + lq + 4 * r;
+        pcv[r] = (col < rankA) ? p1[col < rankA ? col : 0] : 0.0;
+    }
+    const double rxv = (tid < Q2_RB) ? rx[row0 + tid] : 0.0;
     double jt[NTW][4][NP];
 #pragma unroll
     for (int T = 0; T < NTW; ++T)
@@ -111,6 +148,16 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
                 y[1] = (gr + 1 > gc) ? x[q][1] : ((gr + 1 == gc) ? 1.0 : 0.0);
                 *(v4_d2*)&Vs[(jc + 8 * q) * Q2_LDV + 2 * rp] = y;
             }
+        };
+        auto fetch_vt = [&](int tile, v4_d2 (&x)[8]) {     // the same tile of Vt = V T' (dense: no structure to mask in)
+            if (ENLSIP_JQ1_ABLATE == 3) return;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = *(const v4_d2*)((const char*)(VT + (size_t)(8 * q) * n + 16 * tile) + vlane);
+        };
+        auto put_vt = [&](int tile, const v4_d2 (&x)[8]) {
+            if (ENLSIP_JQ1_ABLATE == 3) return;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(v4_d2*)&Vs[(jc + 8 * q) * Q2_LDV + 2 * rp] = x[q];
         };
         auto tile_on = [&](int T) -> bool {               // wave-uniform: V_b is zero above row c0
             const int tile = w + Q2_NW * T;
@@ -179,29 +226,20 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
             }
             __syncthreads();
         }
+        // W2s[reflector][row] = -(sum of the partial slots); wave w takes the fragments jg = w, w + Q2_NW, ...
 #pragma unroll
-        for (int ti = 0; ti < (4 * NP + Q2_NW - 1) / Q2_NW; ++ti) {
-            // the 8 tiles (reflectors 16 jg2 .., row fragment p2) of W2 are dealt to the waves.
-            // A[i = row][k = reflector] = W1[row][k]: element (D row i = lr, reflector k = 4 ks + lq) of a partial sits
-            // at fragment jg = ks >> 2, D lane (lq' = i & 3, lr' = k & 15), register r = i >> 2.
-            const int idx = w + Q2_NW * ti;                 // < 4 NP (wave-uniform)
-            if (idx >= 4 * NP) break;
-            const int jg2 = idx & 3, p2 = idx >> 2;
-            const double* T = TA + (size_t)b * KBLK * KBLK;
-            mfma_d4 t2 = (mfma_d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-            for (int ks = 0; ks < KBLK / 4; ++ks) {
-                const int k = 4 * ks + lq;
-                const double bvt = T[k + (size_t)(16 * jg2 + lr) * KBLK];   // B[k][j] = T[k][j]
-                const int o = ((p2 * 4 + (ks >> 2)) * 4 + (lr >> 2)) * 64 + 16 * (lr & 3) + (k & 15);
-                double av = ush[o];
+        for (int jg = 0; jg < 4; ++jg) {
+            if ((jg % Q2_NW) != w) continue;
 #pragma unroll
-                for (int q = 1; q < NS; ++q) av += ush[q * Q2_PS + o];
-                t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bvt, t2, 0, 0, 0);
-            }
-            // D[i = row (lq + 4 r)][j = reflector 16 jg2 + lr]  ->  W2s[reflector][16 p2 + i]
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W2s[(16 * jg2 + lr) * Q2_LDW + 16 * p2 + lq + 4 * r] = -t2[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int e = ((p * 4 + jg) * 4 + r) * 64 + ln;
+                    double sacc = ush[e];
+#pragma unroll
+                    for (int q = 1; q < NS; ++q) sacc += ush[q * Q2_PS + e];
+                    W2s[(16 * jg + lr) * Q2_LDW + 16 * p + lq + 4 * r] = -sacc;
+                }
         }
         __syncthreads();
         JQ1_STAMP(4);
@@ -209,13 +247,13 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         // ---- phase 3: tile^T += V_b W2^T  (D^T[i = column lq + 4 r][j = row pair lr]) -------------------------
         {
             v4_d2 vx[8];
-            if (tile_on(0)) fetch_v(w, vx);
+            if (tile_on(0)) fetch_vt(w, vx);
 #pragma unroll
             for (int T = 0; T < NTW; ++T) {
                 const int tile = w + Q2_NW * T;
                 if (tile_on(T)) {
-                    put_v(tile, vx);
-                    if (tile_on(T + 1)) fetch_v(tile + Q2_NW, vx);
+                    put_vt(tile, vx);
+                    if (tile_on(T + 1)) fetch_vt(tile + Q2_NW, vx);
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_d4 fr[NP];
 #pragma unroll
@@ -244,7 +282,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
 #pragma unroll
                         for (int p = 0; p < NP; ++p) jt[T][r][p] = fr[p][r];
                 } else if (tile_on(T + 1)) {
-                    fetch_v(tile + Q2_NW, vx);
+                    fetch_vt(tile + Q2_NW, vx);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -256,15 +294,15 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
     // ---- store the tiles, accumulate d = -J1 p1 - rx ---------------------------------------------------------
     double dp[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) dp[p] = 0.0;
+    for (int p = 0; p < NP; ++p) {
+        dp[p] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dp[p] += jt[0][r][p] * pcv[r];
+    }
 #pragma unroll
     for (int T = 0; T < NTW; ++T)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int col = 16 * (w + Q2_NW * T) + lq + 4 * r;
-            const double pc = (col < rankA) ? p1[col < rankA ? col : 0] : 0.0;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) dp[p] += jt[T][r][p] * pc;
             char* dst = (char*)(W + (size_t)(16 * (w + Q2_NW * T) + 4 * r) * ldw + row0) + wlane;   // W 256-byte aligned
             if (ENLSIP_JQ1_ABLATE == 2) { if (jt[T][r][0] == 1.2345) *(double*)dst = 0.0; }
             else if (NP == 2) __builtin_nontemporal_store((v4_d2){jt[T][r][0], jt[T][r][NP - 1]}, (v4_d2*)dst);
@@ -282,7 +320,7 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < Q2_NW; ++q) s += dred[q][tid];
-        W[row + (size_t)n * ldw] = -s - rx[row];
+        W[row + (size_t)n * ldw] = -s - rxv;
     }
     JQ1_STAMP(6);
 }
@@ -296,6 +334,8 @@ inline bool launch_jq1_v2(const JQ1Args& a, int batch, hipStream_t s) {
     // ENLSIP_GN_JQ1_ROWS=16 selects NP = 1
     const char* rv = getenv("ENLSIP_GN_JQ1_ROWS");
     const bool np2 = !(rv && rv[0] == '1');
+    if (!a.VT) return false;
+    hipLaunchKernelGGL(k_vt, dim3((a.n + 63) / 64, batch), dim3(256), 0, s, a);
     dim3 grid(a.m / (np2 ? 32 : 16), batch);
     dim3 blk(256);
     switch (a.n / 128) {

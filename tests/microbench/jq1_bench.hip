@@ -13,7 +13,8 @@ int main(int argc, char** argv) {
     const int batch = argc > 1 ? atoi(argv[1]) : 256;
     const int m = 4096, n = 512, t = 64, ldw = 4128;
     const long long sW = (long long)ldw * (n + 1 + 32), sJ = (long long)m * n;
-    double *J, *W, *FA, *TA, *p1, *rx; ProbState* S;
+    double *J, *W, *FA, *TA, *p1, *rx, *VT; ProbState* S;
+    CK(hipMalloc(&VT, (size_t)n * 64 * batch * 8)); CK(hipMemset(VT, 0, (size_t)n * 64 * batch * 8));
     CK(hipMalloc(&J, sJ * batch * 8)); CK(hipMalloc(&W, sW * batch * 8));
     CK(hipMalloc(&FA, (size_t)n * t * batch * 8)); CK(hipMalloc(&TA, 4096 * batch * 8));
     CK(hipMalloc(&p1, 64 * batch * 8)); CK(hipMalloc(&rx, (size_t)m * batch * 8)); CK(hipMalloc(&S, sizeof(ProbState) * batch));
@@ -24,7 +25,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(S, hs.data(), sizeof(ProbState) * batch, hipMemcpyHostToDevice));
     JQ1Args a{};
     a.m = m; a.n = n; a.kA = t; a.ldw = ldw; a.J = J; a.ldj = m; a.strideJ = sJ; a.rx = rx; a.stride_rx = m;
-    a.FA = FA; a.sFA = (long long)n * t; a.TA = TA; a.sTA = 4096; a.p1 = p1; a.sP1 = 64; a.W = W; a.sW = sW; a.state = S; a.prob0 = 0;
+    a.FA = FA; a.sFA = (long long)n * t; a.TA = TA; a.sTA = 4096; a.p1 = p1; a.sP1 = 64; a.W = W; a.sW = sW; a.state = S; a.prob0 = 0; a.VT = VT; a.sVT = (long long)n * 64;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     if (!launch_jq1_v2(a, batch, 0)) { printf("shape rejected\n"); return 1; }
     CK(hipDeviceSynchronize());
