@@ -45,24 +45,35 @@ constexpr int Q2_VS = KBLK * Q2_LDV;         // doubles per wave image
 // Vt = V T' for one reflector block (kA = 64): Vt[c][k] = sum_{j = k}^{min(c, 63)} V[c][j] T[k][j], V the unit lower
 // trapezoid held in FA, T upper triangular.  One thread per (row c, reflector k); T through LDS.
 __global__ __launch_bounds__(256) void k_vt(JQ1Args a) {
-    __shared__ double Ts[KBLK * (KBLK + 1)];
+    __shared__ __attribute__((aligned(16))) double Ts[KBLK * KBLK];      // Ts[k][j] = T[k][j] (zero below the diagonal)
     const int n = a.n;
     const int prob = blockIdx.y + a.prob0;
     const double* FA = a.FA + prob * a.sFA;
     const double* TA = a.TA + prob * a.sTA;
     double* VT = a.VT + prob * a.sVT;
-    for (int e = threadIdx.x; e < KBLK * KBLK; e += 256) Ts[(e & 63) * (KBLK + 1) + (e >> 6)] = TA[e];   // Ts[k][j] = T[k][j]
-    __syncthreads();
+    for (int e = threadIdx.x; e < KBLK * KBLK; e += 256) {
+        const int k = e & 63, j = e >> 6;                                  // TA[k + j * 64]
+        Ts[k * KBLK + j] = (k <= j) ? TA[e] : 0.0;
+    }
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    if (c >= n) return;
+    const int cc = c < n ? c : n - 1;
+    // the thread's row of V in registers (lanes along rows: coalesced), then 16 reflectors k = g, g + 4, ...
+    double v[KBLK];
+#pragma unroll
+    for (int j = 0; j < KBLK; ++j) {
+        const double x = FA[cc + (size_t)j * n];
+        v[j] = (cc > j) ? x : (cc == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
     for (int k = threadIdx.x >> 6; k < KBLK; k += 4) {
-        double s = 0.0;
-        const int jmax = c < KBLK - 1 ? c : KBLK - 1;
-        for (int j = k; j <= jmax; ++j) {
-            const double v = (c > j) ? FA[c + (size_t)j * n] : 1.0;       // j == c: unit diagonal
-            s += v * Ts[k * (KBLK + 1) + j];
+        const double* tk = Ts + k * KBLK;          // broadcast reads; entries left of the diagonal are zero
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < KBLK; j += 2) {
+            s0 += v[j] * tk[j];
+            s1 += v[j + 1] * tk[j + 1];
         }
-        VT[c + (size_t)k * n] = s;
+        if (c < n) VT[c + (size_t)k * n] = s0 + s1;
     }
 }
 
