@@ -364,7 +364,8 @@ def test_linearity_in_rhs(solver):
     assert rel(p4, p1 + p3) <= 1e-11
 
 
-@pytest.mark.parametrize("m,n,t,G", [(4000, 64, 0, 4), (3001, 48, 5, 3), (20000, 96, 0, 8), (300, 40, 6, 2)])
+@pytest.mark.parametrize("m,n,t,G", [(4000, 64, 0, 4), (3001, 48, 5, 3), (20000, 96, 0, 8), (300, 40, 6, 2),
+                                     (6000, 300, 10, 3), (5000, 600, 4, 2)])     # combine stage: register blocks / > 512 rows
 def test_tsqr_row_shards_match_single_solve(m, n, t, G, solver):
     """Row-sharded TSQR (config C4 structure) rehearsed on one GPU: G local stages + combine must
     reproduce the oracle's p, ranks, pivots and ||d|| of the unsharded problem."""
