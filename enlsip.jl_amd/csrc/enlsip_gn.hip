@@ -444,6 +444,34 @@ static int run_qrcp_persist(enlsip_gn_handle h, int n2_launch) {
 // ---------------------------------------------------------------------------------------------
 // core: device-pointer batched solve
 // ---------------------------------------------------------------------------------------------
+// F_A, rankA, F_L11, b, p1, block T of Q1 for every problem of the batch (plan already made)
+static int run_constraint_stage(enlsip_gn_handle h, long long batch, long long m, long long n, long long t, const double* dAt,
+                                long long ldat, long long strideAt, const double* dcx, double eps_rank, long long dimA_ov) {
+    const Plan& P = h->plan;
+    hipStream_t s = h->stream;
+    ConstraintArgs ca{};
+    ca.n = (int)n; ca.t = (int)t; ca.kA = P.kA; ca.m = (int)m; ca.eps_rank = eps_rank;
+    ca.dimA_override = (int)dimA_ov; ca.code_override = 0;
+    ca.At = dAt; ca.ldat = ldat; ca.strideAt = strideAt; ca.cx = dcx; ca.stride_cx = t;
+    ca.FA = h->FA; ca.sFA = P.sFA; ca.tauA = h->tauA; ca.sTauA = P.sTauA; ca.jpvtA = h->jpvtA; ca.sJA = P.sJA;
+    ca.FL = h->FL; ca.sFL = P.sFL; ca.tauL = h->tauL; ca.sTauL = P.sTauL; ca.jpvtL = h->jpvtL; ca.sJL = P.sJL;
+    ca.TA = h->TA; ca.sTA = P.sTA; ca.p1 = h->p1; ca.sP1 = P.sP1; ca.bvec = h->bvec; ca.sB = P.sB;
+    ca.state = h->state;
+    // F_A of a matrix that does not fit the LDS area of k_constraint: whole matrix in registers (gn_kernels_geqp3_reg.hpp)
+    if (t >= 1 && t <= 64 && n <= 512 && (size_t)n * t > (size_t)CMAT_DOUBLES && !getenv("ENLSIP_GN_FA_L2")) {
+        Geqp3RegArgs ga{};
+        ga.rows = (int)n; ga.cols = (int)t; ga.A = dAt; ga.lda = ldat; ga.strideA = strideAt;
+        ga.F = h->FA; ga.sF = P.sFA; ga.tau = h->tauA; ga.sTau = P.sTauA; ga.jpvt = h->jpvtA; ga.sJ = P.sJA;
+        ga.T = h->TA; ga.sT = P.sTA; ga.prob0 = 0;
+        if (n <= 256) hipLaunchKernelGGL(k_geqp3_reg<4>, dim3((unsigned)batch), dim3(512), 0, s, ga);
+        else hipLaunchKernelGGL(k_geqp3_reg<8>, dim3((unsigned)batch), dim3(512), 0, s, ga);
+        ca.fa_done = 1;
+    }
+    launch_constraint((int)std::max(n, t), (int)batch, s, ca);
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+
 static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long n, long long t,
                      const double* dJ, long long ldj, long long strideJ, const double* drx,
                      const double* dAt, long long ldat, long long strideAt, const double* dcx,
@@ -477,7 +505,12 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
     auto mark = [&](int i) { if (h->profiling) (void)hipEventRecord(h->ev[i], s); };
 
     mark(0);
+    h->constraints_only = false;
     // 1. constraint stage
+    rc = run_constraint_stage(h, batch, m, n, t, dAt, ldat, strideAt, dcx, eps_rank, dimA_ov);
+    if (rc) return rc;
+    mark(1);
+#if 0
     ConstraintArgs ca{};
     ca.n = (int)n; ca.t = (int)t; ca.kA = P.kA; ca.m = (int)m; ca.eps_rank = eps_rank;
     ca.dimA_override = (int)dimA_ov; ca.code_override = 0;
@@ -498,6 +531,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
     }
     launch_constraint((int)std::max(n, t), (int)batch, s, ca);
     mark(1);
+#endif
 
     int n2_launch = (int)(n - P.kA);  // speculate rankA = min(n, t); verified after the solve
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -836,6 +870,46 @@ static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, i
             const ProbState& st = h->h_state[k];
             info[k] = {st.rankA, st.rankJ2, st.code, st.dimA, st.dimJ2, st.status};
         }
+    return 0;
+}
+
+int enlsip_gn_factor_constraints(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const double* At, int64_t ldat,
+                                 const double* cx, double eps_rank, enlsip_gn_info* info) {
+    if (!h) return -1;
+    int rc = check_limits(h, 1, m, n, t);
+    if (rc) return rc;
+    if (t > 0 && (!At || !cx)) return -5;
+    if (t > 0 && ldat < n) return -6;
+    GN_HIP(hipSetDevice(h->device));
+    h->split = 0;
+    rc = make_plan(h, 1, m, n, t);
+    if (rc) return rc;
+    // same staging layout as solve_host, so that a following solve of the same shape reuses the buffers
+    const size_t inJ = (size_t)m * n, inAt = (size_t)n * t;
+    rc = grow(h, h->in_stage, (inJ + (size_t)m + inAt + (size_t)t) * 8 + 1024);
+    if (rc) return rc;
+    double* dAt = (double*)h->in_stage.p + inJ + (size_t)m;
+    double* dcx = dAt + inAt;
+    hipStream_t s = h->stream;
+    if (t > 0) {
+        GN_HIP(hipMemcpy2DAsync(dAt, (size_t)n * 8, At, (size_t)ldat * 8, (size_t)n * 8, (size_t)t, hipMemcpyHostToDevice, s));
+        GN_HIP(hipMemcpyAsync(dcx, cx, (size_t)t * 8, hipMemcpyHostToDevice, s));
+    }
+    h->eps_rank = eps_rank;
+    h->factors_valid = false;
+    h->last_J = nullptr; h->last_rx = nullptr;
+    h->last_cx = dcx; h->last_stride_cx = t;
+    h->last_At = dAt; h->last_ldat = n; h->last_strideAt = (long long)n * t;
+    rc = run_constraint_stage(h, 1, m, n, t, dAt, n, (long long)n * t, dcx, eps_rank, -1);
+    if (rc) return rc;
+    GN_HIP(hipMemcpyAsync(h->h_state, h->state, sizeof(ProbState), hipMemcpyDeviceToHost, s));
+    GN_HIP(hipStreamSynchronize(s));
+    h->factors_valid = true;
+    h->constraints_only = true;
+    if (info) {
+        const ProbState& st = h->h_state[0];
+        *info = {st.rankA, 0, st.code, st.dimA, 0, st.status};
+    }
     return 0;
 }
 

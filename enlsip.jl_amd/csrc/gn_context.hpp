@@ -54,6 +54,7 @@ struct enlsip_gn_context {
     gn::Plan plan;
     bool have_plan = false;
     bool factors_valid = false;
+    bool constraints_only = false;   // resident: F_A, F_L11 only (enlsip_gn_factor_constraints); everything about J is absent
     double eps_rank = 0.0;
 
     // workspace (one allocation, carved)

@@ -223,6 +223,21 @@ function gradient_hip(h::Handle, n::Integer)
     return g
 end
 
+"""    factor_constraints_hip!(h, m, A, cx, ε_rank) -> (rankA, F_A, F_L11)
+
+The constraint stage alone (src/enlsip_functions.jl:700, :768-769): leaves `F_A`, `F_L11` resident for
+`first_lagrange_mult_estimate_hip!` (:704) before any subproblem solve.  `m` = rows of the solve that follows.
+"""
+function factor_constraints_hip!(h::Handle, m::Integer, A::Matrix{Float64}, cx::Vector{Float64}, ε_rank::Float64)
+    t, n = size(A)
+    At = Matrix(transpose(A))
+    info = Ref(Info(0, 0, 0, 0, 0, 0))
+    GC.@preserve At cx check(h, ccall((:enlsip_gn_factor_constraints, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Float64, Ref{Info}),
+        h.ptr, m, n, t, At, max(n, 1), cx, ε_rank, info))
+    return info[].rankA, DeviceQR(h, FACTOR_A, n), DeviceQR(h, FACTOR_L11, t)
+end
+
 """    jacobian_times_hip(h, p, m, t) -> (J*p, C.A*p) on the J and A of the last solve (src/enlsip_functions.jl:2226-2229)"""
 function jacobian_times_hip(h::Handle, p::Vector{Float64}, m::Integer, t::Integer)
     Jp = zeros(Float64, m); Ap = zeros(Float64, t)

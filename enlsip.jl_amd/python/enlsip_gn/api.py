@@ -142,6 +142,19 @@ class GNSolver:
                         int(info.dimJ2), int(info.status), jA, jL, jJ[:n2].copy())
 
     # ---- batch, host buffers ----------------------------------------------------------------
+    def factor_constraints(self, m: int, A: np.ndarray, cx: np.ndarray, eps_rank: float = SQRT_EPS):
+        """Constraint stage alone (src/enlsip_functions.jl:700, :768-769): F_A, rankA, F_L11 left resident for
+        first_lagrange (pass grad_fx) and the F_A / F_L11 accessors.  A: (t, n) active constraint Jacobian; m: rows of the
+        solve that follows.  Returns (rankA, code, dimA)."""
+        A = np.asarray(A, dtype=np.float64)
+        t, n = (A.shape if A.size else (0, A.shape[1] if A.ndim == 2 else 0))
+        At = np.ascontiguousarray(A) if t else None          # (t, n) C-order == column-major n x t
+        cxv = np.ascontiguousarray(cx, dtype=np.float64) if t else None
+        info = L.Info()
+        self._chk(self._lib.enlsip_gn_factor_constraints(self._h, m, n, t, _fptr(At) if t else None, max(n, 1),
+                                                         _fptr(cxv) if t else None, eps_rank, C.byref(info)))
+        return int(info.rankA), int(info.code), int(info.dimA)
+
     def solve_batched(self, J: np.ndarray, rx: np.ndarray, At: np.ndarray, cx: np.ndarray,
                       eps_rank: float = SQRT_EPS):
         """J: (batch, n, m) C-order array holding each m x n problem column-major (i.e. J[k].T is

@@ -198,10 +198,9 @@ def update_working_set(solver: GNSolver, W: WorkingSet, rx, A, C: Constraint, gr
                 rankA = _direction()
         return rankA, lam
 
-    # The reference factors A' first (:700) and only then decides; on the device the factorisation
-    # comes with the full solve, which is exactly the solve of the s == 0 branch (:768-771).
-    rankA = _direction()
-    # first_lagrange_mult_estimate! on the device, from the resident F_A and cx of the solve just done
+    # F_A = qr(C.A', ColumnNorm()) (:700) and first_lagrange_mult_estimate! (:704) on the device, before any solve:
+    # the constraint stage alone leaves F_A resident for the estimate
+    solver.factor_constraints(J.shape[0], C.A, C.cx, eps_rank)
     lam, it.grad_res = solver.first_lagrange(W.t, grad_fx, C.diag_scale if C.scaling else None, eps_rank)
     s = check_constraint_deletion(W.q, C.A, lam, C.scaling, C.diag_scale, it.grad_res)
     if s != 0:                                                         # :706-765
@@ -232,7 +231,8 @@ def update_working_set(solver: GNSolver, W: WorkingSet, rx, A, C: Constraint, gr
             C.A = rows * C.diag_scale[:, None] if C.scaling else rows.copy()
             rankA = _direction()
             rankA, lam = _second_order(rankA, lam)
-    else:                                                              # :767-791 (solve already done)
+    else:                                                              # :767-791
+        rankA = _direction()
         rankA, lam = _second_order(rankA, lam)
     it.lam = lam
     return _views()

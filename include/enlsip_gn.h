@@ -104,6 +104,16 @@ int enlsip_gn_solve(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t,
                     int64_t* jpvtA, int64_t* jpvtL, int64_t* jpvtJ2);
 
 /*
+ * The constraint stage alone: F_A = qr(C.A', ColumnNorm()) (src/enlsip_functions.jl:700), rankA (:768, :17-31) and
+ * F_L11 (:769) of one problem, left resident for enlsip_gn_first_lagrange (pass grad_fx), the F_A / F_L11 accessors and
+ * apply_q / apply_qt — what update_working_set needs BEFORE it decides which constraint to drop (:700-704).  m is the row
+ * count of the solve that follows (the workspace plan is shared).  J-related entries (F_J2, get_JQ1, resolve, gradient,
+ * second estimate, jacobian_times) report an error until the next solve.  info: rankA, code, dimA (J2 fields zero).
+ */
+int enlsip_gn_factor_constraints(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const double* At, int64_t ldat,
+                                 const double* cx, double eps_rank, enlsip_gn_info* info);
+
+/*
  * Batch of independent subproblems of one shape, host buffers.  Problem k uses
  * J + k*strideJ, rx + k*m, At + k*strideAt, cx + k*t; outputs p + k*n, b + k*t, d + k*m,
  * info[k], jpvtA + k*t, jpvtL + k*min(n,t), jpvtJ2 + k*n.

@@ -344,6 +344,34 @@ def test_multiplier_estimates_on_device(kind, m, n, t, scaling, solver):
     assert np.abs(Ap - A @ out.p).max() <= 1e-13 * max(1.0, np.abs(A @ out.p).max())
 
 
+@pytest.mark.parametrize("kind,m,n,t", [("full", 600, 40, 6), ("rankdefA", 300, 30, 9), ("full", 4096, 512, 64), ("full", 50, 20, 30)])
+def test_factor_constraints_alone(kind, m, n, t, solver):
+    """enlsip_gn_factor_constraints: the first factorisation of update_working_set (src/enlsip_functions.jl:700) and the
+    multiplier estimate that follows it (:704), before any solve; J-related entries must refuse."""
+    from enlsip_gn import FACTOR_A, FACTOR_L11, FACTOR_J2, GNError
+    gen = synth.make_rank_deficient_A if kind == "rankdefA" else synth.make_problem
+    J, rx, A, cx = gen(6100 + m + n, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    rankA, code, dimA = solver.factor_constraints(m, A, cx)
+    assert (rankA, code, dimA) == (ref.rankA, ref.code, ref.rankA)
+    for which, F in ((FACTOR_A, ref.F_A), (FACTOR_L11, ref.F_L11)):
+        fv = solver.factor(which)
+        assert rel(np.abs(fv.R), np.abs(F.R)) <= 1e-10 and np.array_equal(fv.p, F.p)
+    grad = J.T @ rx
+    it = go.IterationRecord()
+    lam_ref = go.first_lagrange_mult_estimate(A, grad, cx, False, np.ones(t), ref.F_A, it, go.SQRT_EPS)
+    lam, gres = solver.first_lagrange(t, grad, None)
+    assert rel(lam, lam_ref) <= 1e-9 and abs(gres - it.grad_res) <= 1e-10 * max(1.0, abs(it.grad_res))
+    with pytest.raises(GNError):
+        solver.factor(FACTOR_J2).R
+    with pytest.raises(GNError):
+        solver.second_lagrange(t, ref.p, None)
+    with pytest.raises(GNError):
+        solver.resolve(m, n, t, ref.rankA, ref.rankJ2, -1)
+    out = solver.solve(J, rx, A, cx)                      # a solve afterwards restores the full state
+    assert rel(out.p, ref.p) <= 1e-9 and solver.factor(FACTOR_J2).R.shape == ref.F_J2.R.shape
+
+
 def test_argument_errors(solver):
     from enlsip_gn import GNError
     J, rx, A, cx = synth.make_problem(1, 50, 10, 2)
