@@ -116,6 +116,7 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    step()                  # set-up, not a warm-up step: allocates the handles' workspaces and the second pipeline stream
     for _ in range(args.warmup):
         step()
     barrier()
