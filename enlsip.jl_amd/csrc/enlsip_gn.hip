@@ -510,28 +510,6 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
     rc = run_constraint_stage(h, batch, m, n, t, dAt, ldat, strideAt, dcx, eps_rank, dimA_ov);
     if (rc) return rc;
     mark(1);
-#if 0
-    ConstraintArgs ca{};
-    ca.n = (int)n; ca.t = (int)t; ca.kA = P.kA; ca.m = (int)m; ca.eps_rank = eps_rank;
-    ca.dimA_override = (int)dimA_ov; ca.code_override = 0;
-    ca.At = dAt; ca.ldat = ldat; ca.strideAt = strideAt; ca.cx = dcx; ca.stride_cx = t;
-    ca.FA = h->FA; ca.sFA = P.sFA; ca.tauA = h->tauA; ca.sTauA = P.sTauA; ca.jpvtA = h->jpvtA; ca.sJA = P.sJA;
-    ca.FL = h->FL; ca.sFL = P.sFL; ca.tauL = h->tauL; ca.sTauL = P.sTauL; ca.jpvtL = h->jpvtL; ca.sJL = P.sJL;
-    ca.TA = h->TA; ca.sTA = P.sTA; ca.p1 = h->p1; ca.sP1 = P.sP1; ca.bvec = h->bvec; ca.sB = P.sB;
-    ca.state = h->state;
-    // F_A of a matrix that does not fit the LDS area of k_constraint: whole matrix in registers (gn_kernels_geqp3_reg.hpp)
-    if (t >= 1 && t <= 64 && n <= 512 && (size_t)n * t > (size_t)CMAT_DOUBLES && !getenv("ENLSIP_GN_FA_L2")) {
-        Geqp3RegArgs ga{};
-        ga.rows = (int)n; ga.cols = (int)t; ga.A = dAt; ga.lda = ldat; ga.strideA = strideAt;
-        ga.F = h->FA; ga.sF = P.sFA; ga.tau = h->tauA; ga.sTau = P.sTauA; ga.jpvt = h->jpvtA; ga.sJ = P.sJA;
-        ga.T = h->TA; ga.sT = P.sTA; ga.prob0 = 0;
-        if (n <= 256) hipLaunchKernelGGL(k_geqp3_reg<4>, dim3((unsigned)batch), dim3(512), 0, s, ga);
-        else hipLaunchKernelGGL(k_geqp3_reg<8>, dim3((unsigned)batch), dim3(512), 0, s, ga);
-        ca.fa_done = 1;
-    }
-    launch_constraint((int)std::max(n, t), (int)batch, s, ca);
-    mark(1);
-#endif
 
     int n2_launch = (int)(n - P.kA);  // speculate rankA = min(n, t); verified after the solve
     for (int attempt = 0; attempt < 2; ++attempt) {
