@@ -467,7 +467,8 @@ static int run_constraint_stage(enlsip_gn_handle h, long long batch, long long m
         else hipLaunchKernelGGL(k_geqp3_reg<8>, dim3((unsigned)batch), dim3(512), 0, s, ga);
         ca.fa_done = 1;
     }
-    launch_constraint((int)std::max(n, t), (int)batch, s, ca);
+    // with F_A done the kernel only factors the t x kA matrix R_A': size its rows-per-lane instantiation (and LDS) for that
+    launch_constraint(ca.fa_done ? (int)std::max<long long>(t, 1) : (int)std::max(n, t), (int)batch, s, ca);
     GN_HIP(hipGetLastError());
     return 0;
 }

@@ -48,7 +48,7 @@ inline void constraint_carve(long long n, long long t, int fa_done, int& nv, int
     nv = (int)((mx + 7) / 8 * 8);
     blkd = mx <= 32 ? 32 * 65 : 64 * 65;
     gld = (fa_done || kA == 0) ? 0 : (int)(64 * (kA < 64 ? kA : 64));
-    long long md = n * t > t * kA ? n * t : t * kA;
+    long long md = (!fa_done && n * t > t * kA) ? n * t : t * kA;     // F_A is not staged when k_geqp3_reg produced it
     if (md > CMAT_DOUBLES) md = CMAT_DOUBLES;
     matd = (int)((md + 1) / 2 * 2);
 }
