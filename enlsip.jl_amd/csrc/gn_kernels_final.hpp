@@ -130,7 +130,10 @@ __global__ __launch_bounds__(NTH) void k_pivot_solve(FinalArgs a) {
     for (int i = tid; i < n2; i += nt) pbuf[rankA + (int)jpvtJ[i] - 1] = (i < dimJ2) ? ybuf[i] : 0.0;
     __syncthreads();
     // p = F_A.Q * y
-    if (wave_id() == 0) wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);
+    if (wave_id() == 0) {
+        if (n <= 64 * RPL) wave_apply_reflectors_reg<false, RPL>(FA, n, tauA, kA, n, pbuf);
+        else wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);
+    }
     __syncthreads();
     if (a.p_out)
         for (int i = tid; i < n; i += nt) a.p_out[prob * a.sPo + i] = pbuf[i];

@@ -281,4 +281,42 @@ __device__ void wave_apply_reflectors(const double* __restrict__ F, int ld, cons
     }
 }
 
+// Register form of wave_apply_reflectors for len <= 64 * RPL: the reflector is fetched ONCE (the generic form reads it for
+// the dot product and again for the update, two dependent L2 round trips per reflector) and the next one travels while the
+// current one is applied.  x in LDS, lane ln owns entries ln + 64 i.
+template <bool TRANS, int RPL>
+__device__ void wave_apply_reflectors_reg(const double* __restrict__ F, int ld, const double* __restrict__ tau,
+                                          int k, int len, double* x) {
+    const int ln = lane_id();
+    double xr[RPL], vn[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) xr[i] = (ln + 64 * i < len) ? x[ln + 64 * i] : 0.0;
+    auto fetch = [&](int j, double (&v)[RPL]) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = ln + 64 * i;
+            v[i] = (r > j && r < len) ? F[r + (size_t)j * ld] : 0.0;
+        }
+    };
+    if (k > 0) fetch(TRANS ? 0 : k - 1, vn);
+    for (int s = 0; s < k; ++s) {
+        const int j = TRANS ? s : k - 1 - s;
+        double v[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) v[i] = (ln + 64 * i == j) ? 1.0 : vn[i];
+        if (s + 1 < k) fetch(TRANS ? s + 1 : k - 2 - s, vn);
+        const double tj = tau[j];
+        if (tj == 0.0) continue;
+        double dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) dot += v[i] * xr[i];
+        dot = wave_allsum(dot) * tj;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) xr[i] -= dot * v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RPL; ++i)
+        if (ln + 64 * i < len) x[ln + 64 * i] = xr[i];
+}
+
 }  // namespace gn
