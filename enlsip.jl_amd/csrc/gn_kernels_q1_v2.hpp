@@ -151,6 +151,11 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         auto put_v = [&](int tile, const v4_d2 (&x)[8]) {
             if (ENLSIP_JQ1_ABLATE == 3) return;
             const int gr = 16 * tile + 2 * rp;
+            if (16 * tile >= c0 + KBLK) {          // tile below the trapezoid's triangle (wave-uniform): V is dense there
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *(v4_d2*)&Vs[(jc + 8 * q) * Q2_LDV + 2 * rp] = x[q];
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int gc = c0 + jc + 8 * q;
