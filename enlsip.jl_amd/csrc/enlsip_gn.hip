@@ -20,6 +20,7 @@
 #include "gn_kernels_q1_rows.hpp"
 #include "gn_kernels_final_small.hpp"
 #include "gn_kernels_constraint_small.hpp"
+#include "gn_kernels_constraint_dist.hpp"
 #include "gn_kernels_update_v4.hpp"
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_lagrange.hpp"
@@ -185,7 +186,7 @@ static void big_lds(KernelT k, size_t bytes) {
 // small problems (C3, C5) keep several workgroups resident per CU; larger ones use 1024 threads.
 static void launch_constraint(int rows, int batch, hipStream_t s, ConstraintArgs a) {
     if (launch_constraint_small(batch, s, a)) return;
-    constraint_carve(a.n, a.t, a.fa_done, a.nv, a.blkd, a.gld, a.matd);
+    constraint_carve(a.n, a.t, a.fa_done, a.nv, a.blkd, a.gld, a.matd, a.need_T, a.fl_done);
     const size_t lds = constraint_lds_bytes(a.nv, a.blkd, a.gld, a.matd);
     if (rows <= 32) GN_LAUNCH_BIG((k_constraint<1, 8, 256>), dim3(batch), dim3(256), lds, s, a);
     else if (rows <= 64) GN_LAUNCH_BIG((k_constraint<1, 8, 512>), dim3(batch), dim3(512), lds, s, a);
@@ -444,11 +445,91 @@ static int run_qrcp_persist(enlsip_gn_handle h, int n2_launch) {
 // ---------------------------------------------------------------------------------------------
 // core: device-pointer batched solve
 // ---------------------------------------------------------------------------------------------
+// Constraint stage with many constraints: both pivoted factorisations through the distributed QR (one launch per pivot step),
+// then k_constraint only does the rank decisions, the triangular solves and the T blocks.
+static int run_constraint_dist(enlsip_gn_handle h, ConstraintArgs ca, long long batch, long long n, long long t) {
+    const Plan& P = h->plan;
+    hipStream_t s = h->stream;
+    const int kA = P.kA;
+    auto pad = [](long long x) { return rup(std::max<long long>(x, 1), 32); };
+    const long long ldc = rup(std::max(n, t), 8);
+    const long long sMc = pad(ldc * (t + 2)), sVbc = pad(ldc * (kA + 1)), sRtc = pad(ldc * (t + 2)), sLc = pad(ldc * (kA + 1));
+    const long long sVec = pad(std::max(n, t) + 1), sIc = pad(t + 1);
+    const int Gc = (int)((t + 1 + QD_CPW - 1) / QD_CPW);
+    const long long sCandc = 2LL * Gc;
+    const size_t bytes = (size_t)batch * ((sMc + sVbc + sRtc + sLc + 5 * sVec) * 8 + 5 * sIc * 4 + sCandc * sizeof(QdCand) +
+                                          2 * sizeof(ProbState)) + 4096;
+    int rc = grow(h, h->cws, bytes);
+    if (rc) return rc;
+    char* p = (char*)h->cws.p;
+    auto carve = [&](size_t b) { char* r = p; p += (b + 255) / 256 * 256; return r; };
+    double* cM = (double*)carve((size_t)batch * sMc * 8);
+    double* cVb = (double*)carve((size_t)batch * sVbc * 8);
+    double* cRt = (double*)carve((size_t)batch * sRtc * 8);
+    double* cL = (double*)carve((size_t)batch * sLc * 8);
+    double* cDiag = (double*)carve((size_t)batch * sVec * 8);
+    double* cVn1 = (double*)carve((size_t)batch * sVec * 8);
+    double* cVn2 = (double*)carve((size_t)batch * sVec * 8);
+    double* cBq = (double*)carve((size_t)batch * sVec * 8);       // b_buff, later F_L11.Q' b_buff
+    double* cQb = (double*)carve((size_t)batch * sVec * 8);
+    int* cChosen = (int*)carve((size_t)batch * sIc * 4);
+    int* cPos = (int*)carve((size_t)batch * 2 * sIc * 4);
+    int* cColat = (int*)carve((size_t)batch * 2 * sIc * 4);
+    QdCand* cCand = (QdCand*)carve((size_t)batch * sCandc * sizeof(QdCand));
+    ProbState* stA = (ProbState*)carve((size_t)batch * sizeof(ProbState));
+    ProbState* stL = (ProbState*)carve((size_t)batch * sizeof(ProbState));
+    const unsigned gb = (unsigned)((batch + 255) / 256);
+    hipLaunchKernelGGL(k_fake_state, dim3(gb), dim3(256), 0, s, stA, (int)batch, kA, (int)t);
+    hipLaunchKernelGGL(k_fake_state, dim3(gb), dim3(256), 0, s, stL, (int)batch, kA, kA);
+
+    QdArgs q{};
+    q.n = (int)n; q.ldw = 0; q.ldr = (int)ldc; q.prob0 = 0;
+    q.M = cM; q.sM = sMc; q.Vb = cVb; q.sVb = sVbc; q.Rt = cRt; q.sRt = sRtc;
+    q.diag = cDiag; q.sDiag = sVec; q.vn1 = cVn1; q.vn2 = cVn2; q.sVn = sVec;
+    q.chosen = cChosen; q.pos = cPos; q.colat = cColat; q.sI = sIc;
+    q.cand = cCand; q.sCand = sCandc; q.Gmax = Gc;
+    auto factor = [&](int rows, int cols, int steps) {
+        const dim3 grid((cols + 1 + QD_CPW - 1) / QD_CPW, (unsigned)batch);
+        const bool big = rows > 512;
+        q.step = 0;
+        if (big) hipLaunchKernelGGL(k_qd_init<16>, grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, s, q);
+        for (int j = 0; j < steps; ++j) {
+            q.step = j;
+            if (big) hipLaunchKernelGGL(k_qd_step<16>, grid, dim3(256), 0, s, q);
+            else hipLaunchKernelGGL(k_qd_step<8>, grid, dim3(256), 0, s, q);
+        }
+        q.step = 0;
+        hipLaunchKernelGGL(k_qd_assemble, grid, dim3(256), 0, s, q);
+    };
+    // ---- F_A: the n x t matrix C.A' -------------------------------------------------------------------------------
+    q.rows = (int)n; q.in_mode = 1; q.Ain = ca.At; q.ldain = ca.ldat; q.sAin = ca.strideAt;
+    q.tau = h->tauA; q.sTau = P.sTauA; q.jpvt = h->jpvtA; q.sJ = P.sJA; q.state = stA;
+    factor((int)n, (int)t, kA);
+    hipLaunchKernelGGL(k_copy_cols, dim3((unsigned)t, (unsigned)batch), dim3(256), 0, s, h->FA, n, P.sFA, cRt, ldc, sRtc, (int)n, (int)t);
+    // ---- F_L11: the t x kA lower trapezoid R_A', carrying b_buff = -cx[F_A.p] ----------------------------------------
+    hipLaunchKernelGGL(k_bbuff, dim3((unsigned)((t + 255) / 256), (unsigned)batch), dim3(256), 0, s, cBq, sVec, ca.cx, ca.stride_cx,
+                       h->jpvtA, P.sJA, (int)t);
+    q.rows = (int)t; q.in_mode = 2; q.Ain = h->FA; q.ldain = n; q.sAin = P.sFA; q.rin = cBq; q.sRin = sVec; q.Lout = cL; q.sLout = sLc;
+    q.tau = h->tauL; q.sTau = P.sTauL; q.jpvt = h->jpvtL; q.sJ = P.sJL; q.state = stL;
+    factor((int)t, kA, (int)std::min<long long>(t, kA));
+    hipLaunchKernelGGL(k_copy_cols, dim3((unsigned)kA, (unsigned)batch), dim3(256), 0, s, h->FL, t, P.sFL, cRt, ldc, sRtc, (int)t, kA);
+    hipLaunchKernelGGL(k_copy_cols, dim3(1, (unsigned)batch), dim3(256), 0, s, cQb, sVec, sVec, cRt + (size_t)kA * ldc, ldc, sRtc, (int)t, 1);
+    // ---- ranks, triangular solves, T blocks ---------------------------------------------------------------------------
+    ca.fa_done = 1; ca.fl_done = 1; ca.need_T = 1;
+    ca.Lmat = cL; ca.ldL = ldc; ca.sL = sLc; ca.qb = cQb; ca.sQb = sVec;
+    h->cdist.L = cL; h->cdist.ldL = ldc; h->cdist.sL = sLc; h->cdist.qb = cQb; h->cdist.sQb = sVec; h->cdist.valid = true;
+    launch_constraint((int)std::max(n, t), (int)batch, s, ca);
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+
 // F_A, rankA, F_L11, b, p1, block T of Q1 for every problem of the batch (plan already made)
 static int run_constraint_stage(enlsip_gn_handle h, long long batch, long long m, long long n, long long t, const double* dAt,
                                 long long ldat, long long strideAt, const double* dcx, double eps_rank, long long dimA_ov) {
     const Plan& P = h->plan;
     hipStream_t s = h->stream;
+    h->cdist.valid = false;
     ConstraintArgs ca{};
     ca.n = (int)n; ca.t = (int)t; ca.kA = P.kA; ca.m = (int)m; ca.eps_rank = eps_rank;
     ca.dimA_override = (int)dimA_ov; ca.code_override = 0;
@@ -457,6 +538,8 @@ static int run_constraint_stage(enlsip_gn_handle h, long long batch, long long m
     ca.FL = h->FL; ca.sFL = P.sFL; ca.tauL = h->tauL; ca.sTauL = P.sTauL; ca.jpvtL = h->jpvtL; ca.sJL = P.sJL;
     ca.TA = h->TA; ca.sTA = P.sTA; ca.p1 = h->p1; ca.sP1 = P.sP1; ca.bvec = h->bvec; ca.sB = P.sB;
     ca.state = h->state;
+    // many constraints: both factorisations through the distributed pivoted QR
+    if (t > 64 && (size_t)n * t > (size_t)CMAT_DOUBLES && !getenv("ENLSIP_GN_FA_L2")) return run_constraint_dist(h, ca, batch, n, t);
     // F_A of a matrix that does not fit the LDS area of k_constraint: whole matrix in registers (gn_kernels_geqp3_reg.hpp)
     if (t >= 1 && t <= 64 && n <= 512 && (size_t)n * t > (size_t)CMAT_DOUBLES && !getenv("ENLSIP_GN_FA_L2")) {
         Geqp3RegArgs ga{};
@@ -693,6 +776,7 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->in_stage.p) (void)hipFree(h->in_stage.p);
     if (h->out_stage.p) (void)hipFree(h->out_stage.p);
     if (h->lag.p) (void)hipFree(h->lag.p);
+    if (h->cws.p) (void)hipFree(h->cws.p);
     if (h->scratch.p) (void)hipFree(h->scratch.p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_sbinfo) (void)hipHostFree(h->h_sbinfo);

@@ -54,6 +54,12 @@ struct enlsip_gn_context {
     gn::Plan plan;
     bool have_plan = false;
     bool factors_valid = false;
+    gn::DevBuf cws;                      // workspace of the distributed constraint stage (many constraints)
+    struct {                             // what the re-solve needs of it: unfactored L11 and F_L11.Q' b_buff of the last solve
+        const double* L = nullptr; long long ldL = 0, sL = 0;
+        const double* qb = nullptr; long long sQb = 0;
+        bool valid = false;
+    } cdist;
     bool constraints_only = false;   // resident: F_A, F_L11 only (enlsip_gn_factor_constraints); everything about J is absent
     double eps_rank = 0.0;
 

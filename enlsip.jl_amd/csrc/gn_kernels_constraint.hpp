@@ -23,6 +23,11 @@ struct ConstraintArgs {
     int prob0;           // problem index offset
     int fa_done;         // 1: F_A, tau_A, jpvt_A and the block T factor were produced by k_geqp3_reg
     int nv, blkd, gld, matd;   // LDS carve in doubles (constraint_carve)
+    // many constraints (run_constraint_dist): both factorisations were produced by the distributed pivoted QR
+    int fl_done;         // 1: F_L11, tau_L, jpvt_L are final; Lmat = the unfactored L11 = R_A' (ld ldL), qb = F_L11.Q' b_buff (t)
+    int need_T;          // 1: build the block T factors of Q1 here although F_A was produced elsewhere
+    const double* Lmat;  long long ldL, sL;
+    const double* qb;    long long sQb;
     // inputs
     const double* At;    long long ldat, strideAt;   // n x t
     const double* cx;    long long stride_cx;        // t
@@ -42,13 +47,15 @@ struct ConstraintArgs {
 // LDS carve (doubles): vn1[nv] vn2[nv] ybuf[nv] blk[blkd] gl[gld] mat[matd] + ints, sized by the host to the problem
 // (small problems then run several workgroups per CU).  blk: 64 x 65 diagonal block of the triangular solves, the
 // 32 x 65 staging chunk of V and the 64-strided T image; gl: 64-strided Gram matrix of one reflector block.
-inline void constraint_carve(long long n, long long t, int fa_done, int& nv, int& blkd, int& gld, int& matd) {
+inline void constraint_carve(long long n, long long t, int fa_done, int& nv, int& blkd, int& gld, int& matd, int need_T = 0,
+                             int fl_done = 0) {
     const long long mx = n > t ? n : t;
     const long long kA = n < t ? n : t;
     nv = (int)((mx + 7) / 8 * 8);
     blkd = mx <= 32 ? 32 * 65 : 64 * 65;
-    gld = (fa_done || kA == 0) ? 0 : (int)(64 * (kA < 64 ? kA : 64));
+    gld = ((fa_done && !need_T) || kA == 0) ? 0 : (int)(64 * (kA < 64 ? kA : 64));
     long long md = (!fa_done && n * t > t * kA) ? n * t : t * kA;     // F_A is not staged when k_geqp3_reg produced it
+    if (fl_done) md = 2;                                               // nothing is staged at all
     if (md > CMAT_DOUBLES) md = CMAT_DOUBLES;
     matd = (int)((md + 1) / 2 * 2);
 }
@@ -110,11 +117,13 @@ __global__ __launch_bounds__(NTH) void k_constraint(ConstraintArgs a) {
     const int dimA = (a.dimA_override >= 0) ? a.dimA_override : rankA;
 
     // ---- L11 = R_A'  (t x kA, lower trapezoid) ---------------------------------------------
-    const bool fl_lds = (size_t)t * kA <= (size_t)CMAT_DOUBLES;
+    const bool fl_lds = !a.fl_done && (size_t)t * kA <= (size_t)CMAT_DOUBLES;
     double* WL = fl_lds ? mat : FL;
-    for (int e = tid; e < t * kA; e += nt) {
-        const int i = e % t, j = e / t;  // L[i][j] = R[j][i], j <= i
-        WL[i + (size_t)j * t] = (j <= i) ? FA[j + (size_t)i * n] : 0.0;
+    if (!a.fl_done) {
+        for (int e = tid; e < t * kA; e += nt) {
+            const int i = e % t, j = e / t;  // L[i][j] = R[j][i], j <= i
+            WL[i + (size_t)j * t] = (j <= i) ? FA[j + (size_t)i * n] : 0.0;
+        }
     }
     // b_buff = -cx[F_A.p]
     for (int i = tid; i < t; i += nt) ybuf[i] = -cx[jpvtA[i] - 1];
@@ -123,20 +132,25 @@ __global__ __launch_bounds__(NTH) void k_constraint(ConstraintArgs a) {
         // b = -cx[p]; p1 = LowerTriangular(R') \ b        (:132-133)
         for (int i = tid; i < t; i += nt) bvec[i] = ybuf[i];
         __syncthreads();
-        wg_trsv<true>(WL, t, t, ybuf, blk, &sh_i[2]);
+        if (a.fl_done) wg_trsv<true>(a.Lmat + prob * a.sL, (int)a.ldL, t, ybuf, blk, &sh_i[2]);
+        else wg_trsv<true>(WL, t, t, ybuf, blk, &sh_i[2]);
         for (int i = tid; i < t; i += nt) p1[i] = ybuf[i];
         __syncthreads();
     }
     // ---- F_L11 -----------------------------------------------------------------------------
-    if (t > 0 && kA > 0) wg_geqp2<RPL, G>(WL, t, t, kA, 0, tauL, jpvtL, vn1, vn2, sh_i);
-    if (fl_lds) {
-        for (int e = tid; e < t * kA; e += nt) FL[e] = mat[e];
+    if (!a.fl_done) {
+        if (t > 0 && kA > 0) wg_geqp2<RPL, G>(WL, t, t, kA, 0, tauL, jpvtL, vn1, vn2, sh_i);
+        if (fl_lds) {
+            for (int e = tid; e < t * kA; e += nt) FL[e] = mat[e];
+        }
     }
     __syncthreads();
     if (code == -1) {
         // b = F_L11.Q' * b_buff ; dp1 = U(R_L[1:dimA,1:dimA]) \ b[1:dimA] ;
         // p1 = ([dp1; 0][invperm(F_L11.p)])[1:rankA]       (:141-144)
-        if (wave_id() == 0) wave_apply_reflectors<true>(WL, t, tauL, kA, t, ybuf);
+        if (a.fl_done) {
+            for (int i = tid; i < t; i += nt) ybuf[i] = a.qb[prob * a.sQb + i];   // carried through the factorisation
+        } else if (wave_id() == 0) wave_apply_reflectors<true>(WL, t, tauL, kA, t, ybuf);
         __syncthreads();
         for (int i = tid; i < t; i += nt) bvec[i] = ybuf[i];
         __syncthreads();
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(NTH) void k_constraint(ConstraintArgs a) {
 
     // ---- block T factors of Q1 (dlarft, forward columnwise), KBLK reflectors per block --------
     // Gram G = V'V accumulated from 32-row chunks of V staged in LDS; T recurrence in LDS.
-    const int nblk = a.fa_done ? 0 : (kA + KBLK - 1) / KBLK;
+    const int nblk = (a.fa_done && !a.need_T) ? 0 : (kA + KBLK - 1) / KBLK;
     for (int blkid = 0; blkid < nblk; ++blkid) {
         const int c0 = blkid * KBLK;
         const int kb = (kA - c0) < KBLK ? (kA - c0) : KBLK;

@@ -40,7 +40,21 @@ struct QdArgs {
     int Gmax;
     long long* jpvt;  long long sJ;
     const ProbState* state;
+    // General (tall) inputs — the constraint stage with many constraints (run_constraint_dist): the matrix has `rows` rows,
+    // state.n2 columns (+ one carried column) and min(rows, n2) pivot steps.  rows = 0: the R0 case, rows = steps = state.kp.
+    int rows;
+    int in_mode;       // k_qd_init: 0 = R0 out of the CAQR storage W; 1 = dense Ain (rows x n2, ld ldain), carried column zero;
+                       // 2 = lower trapezoid L[i][j] = (j <= i) ? Ain[j + i * ldain] : 0 (the transposed R of a factor),
+                       //     carried column rin; the unfactored L is also kept in Lout (ld ldr)
+    const double* Ain; long long ldain, sAin;
+    const double* rin; long long sRin;
+    double* Lout;      long long sLout;
 };
+
+__device__ __forceinline__ int qd_rows(const QdArgs& a, int kp) { return a.rows > 0 ? a.rows : kp; }
+__device__ __forceinline__ int qd_steps(const QdArgs& a, int kp, int n2) {
+    return a.rows > 0 ? (a.rows < n2 ? a.rows : n2) : kp;
+}
 
 __device__ __forceinline__ bool qd_better(double v, int p, double bv, int bp) {
     return v > bv || (v == bv && p < bp);
@@ -53,7 +67,8 @@ __global__ __launch_bounds__(256) void k_qd_init(QdArgs a) {
     __shared__ int cpos[QD_CPW];
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
-    const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
+    const int n2 = st.n2, ctot = n2 + 1;
+    const int kp = qd_rows(a, st.kp);          // rows of the matrix
     const int g = blockIdx.x;
     if (kp == 0 || g * QD_CPW >= ctot) return;
     const int ln = lane_id(), w = wave_id();
@@ -69,7 +84,16 @@ __global__ __launch_bounds__(256) void k_qd_init(QdArgs a) {
                 const int r = ln + 64 * i;
                 if (r < kp) {
                     double v;
-                    if (c < n2) v = (r <= c) ? W[r + (size_t)(st.rankA + c) * a.ldw] : 0.0;
+                    if (a.in_mode == 1) {
+                        v = (c < n2) ? a.Ain[prob * a.sAin + r + (size_t)c * a.ldain] : 0.0;
+                    } else if (a.in_mode == 2) {
+                        if (c < n2) {
+                            v = (c <= r) ? a.Ain[prob * a.sAin + c + (size_t)r * a.ldain] : 0.0;
+                            a.Lout[prob * a.sLout + r + (size_t)c * a.ldr] = v;
+                        } else {
+                            v = a.rin[prob * a.sRin + r];
+                        }
+                    } else if (c < n2) v = (r <= c) ? W[r + (size_t)(st.rankA + c) * a.ldw] : 0.0;
                     else v = W[r + (size_t)a.n * a.ldw];
                     M[r + (size_t)c * a.ldr] = v;
                     s += v * v;
@@ -114,10 +138,11 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
     __shared__ int cpos[QD_CPW];
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
-    const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
+    const int n2 = st.n2, ctot = n2 + 1;
+    const int kp = qd_rows(a, st.kp);          // rows of the matrix (= number of steps in the R0 case)
     const int j = a.step;
     const int g = blockIdx.x;
-    if (j >= kp || g * QD_CPW >= ctot) return;
+    if (j >= qd_steps(a, st.kp, n2) || g * QD_CPW >= ctot) return;
     const int gact = (ctot + QD_CPW - 1) / QD_CPW;
     const int ln = lane_id(), w = wave_id();
     const int par = j & 1;
@@ -298,10 +323,12 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
 __global__ __launch_bounds__(256) void k_qd_assemble(QdArgs a) {
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
-    const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
+    const int n2 = st.n2, ctot = n2 + 1;
+    const int kp = qd_rows(a, st.kp);
+    const int nst = qd_steps(a, st.kp, n2);
     const int g = blockIdx.x;
     if (kp == 0 || g * QD_CPW >= ctot) return;
-    const int par = (a.step < 0) ? 0 : (kp & 1);   // block form keeps a single (parity 0) map
+    const int par = (a.step < 0) ? 0 : (nst & 1);   // block form keeps a single (parity 0) map
     const int* colat = a.colat + prob * 2 * a.sI + par * a.sI;
     const double* M = a.M + prob * a.sM;
     const double* Vb = a.Vb + prob * a.sVb;
@@ -313,7 +340,7 @@ __global__ __launch_bounds__(256) void k_qd_assemble(QdArgs a) {
         const int c = (k < n2) ? colat[k] : n2;
         for (int r = ln; r < kp; r += WAVE) {
             double v;
-            if (k < kp && k < n2) {
+            if (k < nst) {
                 if (r < k) v = M[r + (size_t)c * a.ldr];
                 else if (r == k) v = a.diag[prob * a.sDiag + k];
                 else v = Vb[r + (size_t)k * a.ldr];

@@ -26,9 +26,10 @@ def main():
         elif cls == 1:    # small wave kernels
             n = int(rng.integers(8, 65)); m = int(rng.integers(n // 2 + 1, 700)); t = int(rng.integers(0, min(n, 63) + 1))
         elif cls == 2:    # mid
-            n = int(rng.integers(65, 300)); m = int(rng.integers(n, 2500)); t = int(rng.integers(0, min(n, 80)))
-        elif cls == 3:    # register paths / wide
-            n = int(rng.integers(300, 640)); m = int(rng.integers(200, 1800)); t = int(rng.integers(0, 70))
+            n = int(rng.integers(65, 300)); m = int(rng.integers(n, 2500)); t = int(rng.integers(0, min(n, 80) if rng.integers(0, 2) else n + 20))
+        elif cls == 3:    # register paths / wide / many constraints
+            n = int(rng.integers(300, 640)); m = int(rng.integers(200, 1800))
+            t = int(rng.integers(0, 70)) if rng.integers(0, 3) else int(rng.integers(65, 400))
         else:             # m < n
             n = int(rng.integers(20, 200)); m = int(rng.integers(1, n)); t = int(rng.integers(0, min(n, 40)))
         kind = ["full", "full", "full", "rankdefA", "rankdefJ", "graded"][int(rng.integers(0, 6))]

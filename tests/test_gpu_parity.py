@@ -154,14 +154,15 @@ def test_accessors(solver):
     assert rel(R.T @ R, G) <= 1e-12
 
 
-def test_resolve_truncated_dims(solver):
+@pytest.mark.parametrize("m,n,t,dims", [(600, 40, 6, ((6, 34), (4, 20), (0, 0), (6, 10))),
+                                        (700, 300, 100, ((100, 200), (60, 150), (0, 0), (100, 10)))])   # 2nd: distributed constraint stage
+def test_resolve_truncated_dims(m, n, t, dims, solver):
     """sub_search_direction re-entry (src/enlsip_functions.jl:1253) with dimA/dimJ2 below the ranks."""
-    m, n, t = 600, 40, 6
     J, rx, A, cx = synth.make_problem(43, m, n, t)
     ref = go.gn_subproblem(J, rx, A, cx)
     solver.solve(J, rx, A, cx)
     JQ1 = ref.F_A.rmul_Q(J)
-    for dimA, dimJ2 in ((6, 34), (4, 20), (0, 0), (6, 10)):
+    for dimA, dimJ2 in dims:
         p_ref, b_ref, d_ref = go.sub_search_direction(JQ1[:, :ref.rankA], rx, cx, ref.F_A, ref.F_L11, ref.F_J2,
                                                       n, t, ref.rankA, dimA, dimJ2, -1)
         p, b, d = solver.resolve(m, n, t, dimA, dimJ2, -1)
@@ -234,6 +235,10 @@ def test_pipelined_device_batch_matches_oracle(solver):
     ("full", 513, 140, 0),           # no constraints, one row past a tile boundary
     ("full", 1300, 600, 8),          # kp = 592 > 512 rows: launch-per-step pivoted QR (k_qd_*)
     ("rankdefJ", 1100, 560, 6),      # the same path with a rank-deficient J2
+    ("full", 900, 400, 120),         # many constraints: F_A and F_L11 through the distributed pivoted QR
+    ("rankdefA", 700, 300, 100),     # ... with a rank-deficient A (code -1: F_L11.Q' b carried through the factorisation)
+    ("full", 600, 150, 200),         # ... with t > n (kA = n)
+    ("full", 1100, 1000, 700),       # ... with more than 512 rows (16 rows per lane)
 ])
 def test_shape_sweep_register_paths(kind, m, n, t, solver):
     """Shapes chosen to run the register-resident factorisations (k_geqp3_reg, k_sb_factor_reg), the gathered block
