@@ -11,6 +11,13 @@ for p in (ROOT, ROOT / "enlsip.jl_amd" / "python"):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # the oracle's LAPACK calls: at most 16 BLAS threads (the GPU box grants a 16-core share while showing 256 cores;
+    # oversubscribed BLAS workers keep spinning after a call and starve the HIP runtime's submission thread)
+    try:
+        from threadpoolctl import threadpool_limits
+        config._blas_limit = threadpool_limits(limits=16, user_api="blas")
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
