@@ -172,8 +172,8 @@ def test_resolve_truncated_dims(m, n, t, dims, solver):
         assert rel(np.abs(d[:dimJ2]), np.abs(d_ref[:dimJ2])) <= 1e-10
 
 
-def test_batched_matches_single(solver):
-    batch, m, n, t = 5, 300, 24, 3
+@pytest.mark.parametrize("batch,m,n,t", [(5, 300, 24, 3), (4, 500, 200, 100)])     # 2nd: distributed constraint stage, batched
+def test_batched_matches_single(batch, m, n, t, solver):
     Js, rxs, Ats, cxs, refs = [], [], [], [], []
     for k in range(batch):
         J, rx, A, cx = (synth.make_rank_deficient_A if k == 2 else synth.make_problem)(600 + k, m, n, t)
@@ -185,7 +185,7 @@ def test_batched_matches_single(solver):
     p, b, d, infos, jA, jL, jJ = solver.solve_batched(np.stack(Js), np.stack(rxs), np.stack(Ats), np.stack(cxs))
     for k, ref in enumerate(refs):
         assert infos[k][0] == ref.rankA and infos[k][1] == ref.rankJ2 and infos[k][2] == ref.code
-        assert rel(p[k], ref.p) <= TOL_P
+        assert rel(p[k], ref.p) <= (TOL_P if ref.code == 1 else 1e-9)
         if ref.code == 1:
             assert np.array_equal(jJ[k][:n - ref.rankA], ref.jpvtJ2)
 
