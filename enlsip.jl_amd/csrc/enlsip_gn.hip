@@ -307,6 +307,7 @@ static int run_qrcp_dist(enlsip_gn_handle h, int n2_launch) {
     a.chosen = h->qdChosen; a.pos = h->qdPos; a.colat = h->qdColat; a.sI = P.sQI;
     a.cand = (QdCand*)h->qdCand; a.sCand = P.sCand; a.Gmax = P.qdGmax;
     a.jpvt = h->jpvtJ; a.sJ = P.sJJ; a.state = h->state;
+    a.n2cap = n2_launch;
     const int G = (n2_launch + 1 + QD_CPW - 1) / QD_CPW;
     dim3 grid(G, (unsigned)P.batch);
     const bool big = kp_launch > 512;
@@ -336,6 +337,7 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     q.chosen = h->qdChosen; q.pos = h->qdPos; q.colat = h->qdColat; q.sI = P.sQI;
     q.cand = (QdCand*)h->qdCand; q.sCand = P.sCand; q.Gmax = P.qdGmax;
     q.jpvt = h->jpvtJ; q.sJ = P.sJJ; q.state = h->state;
+    q.n2cap = n2_launch;
     a.info = (SbInfo*)h->sbInfo; a.inblk = h->sbInblk; a.sIn = P.sQI; a.blkid = 0;
     a.Tsb = h->sbT; a.sTsb = PB * PB; a.act = h->sbAct; a.sAct = P.sQI + 32;
     const bool blk_update = !big_kp(kp_launch) && !getenv("ENLSIP_GN_SB_STEPWISE");   // MFMA block update (kp <= 512)
@@ -383,7 +385,8 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
         GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)P.batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
         GN_HIP(hipStreamSynchronize(s));
         bool done = true;
-        for (long long k = 0; k < P.batch; ++k) done = done && (hinfo[k].j0 >= h->h_state[k].kp);
+        for (long long k = 0; k < P.batch; ++k)
+            done = done && (h->h_state[k].n2 > n2_launch || hinfo[k].j0 >= h->h_state[k].kp);   // wider problems are skipped here
         if (done) {
             int used = 0;
             for (long long k = 0; k < P.batch; ++k) used = std::max(used, hinfo[k].blk + 1);
@@ -427,6 +430,7 @@ static int run_qrcp_persist(enlsip_gn_handle h, int n2_launch) {
     a.W = h->W; a.sW = P.sW; a.Rt = h->Rt; a.sRt = P.sRt; a.tau = h->tauJ; a.sTau = P.sTauJ;
     a.jpvt = h->jpvtJ; a.sJ = P.sJJ; a.hdr = (QpHeader*)h->qdCand; a.sHdr = P.sCand;
     a.xbuf = h->qdM; a.sX = P.sM; a.abort_word = h->abort_word; a.state = h->state; a.spin_limit = 1 << 20;
+    a.n2cap = n2_launch;
     GN_HIP(hipMemsetAsync(h->qdCand, 0, (size_t)P.batch * P.sCand * sizeof(QpHeader), h->stream));
     GN_HIP(hipMemsetAsync(h->abort_word, 0, 16, h->stream));
     const bool big = kp_launch > 512;
@@ -626,6 +630,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         fa.jL_out = djL; fa.sJLo = P.kA; fa.jpvtL = h->jpvtL; fa.sJL = P.sJL;
         fa.jJ_out = djJ; fa.sJJo = n;
         fa.state = h->state;
+        fa.n2cap = n2_launch;
         {
             const int kp_launch = (int)std::min<long long>(m, n2_launch);
             if ((size_t)kp_launch * (n2_launch + 1) > (size_t)CMAT_DOUBLES) {

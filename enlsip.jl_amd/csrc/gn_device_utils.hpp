@@ -141,6 +141,11 @@ __device__ __forceinline__ int dpp_i32(int x) {
     return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
 }
 
+// Pivot key of a partial column norm: a NaN norm (NaN / Inf in the input) ranks as +infinity, so that a pivot search always
+// returns one of its candidates — with plain comparisons a NaN never wins and the search comes back empty (index -1), which
+// the callers would use as a column index.
+__device__ __forceinline__ double pivot_key(double norm) { return (norm != norm) ? __builtin_huge_val() : norm; }
+
 // Wave arg-max with LAPACK's idamax tie rule on (value, position): larger value wins, equal values
 // -> lower position wins.  Returns the same (val, pos, idx) in every lane.  DPP butterflies inside
 // the rows of 16 lanes, then the four row winners are combined through SGPRs.

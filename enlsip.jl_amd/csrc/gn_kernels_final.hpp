@@ -20,6 +20,7 @@ struct FinalArgs {
     int refactor;         // 1: extract R0 and factor it here; 2: Rt already factored (distributed path);
                           // 0: reuse resident Rt (resolve path)
     int prob0;            // problem index offset
+    int n2cap;            // > 0: launch shape of the stage; wider problems (state.n2 > n2cap) are skipped (redone by the caller)
     int nv, matd;         // LDS carve: vector length (>= max(n, t)) and matrix/diagonal-block area in doubles
     const double* dsrc;   // refactor == 0: transformed right-hand side Q3'd (length m, one problem)
     const double* W;   long long sW;      // ldw x (n+1): R0 in the upper triangle of the J2 columns, d in column n
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(NTH) void k_pivot_solve(FinalArgs a) {
 
     const int prob = blockIdx.x + a.prob0;
     ProbState* stp = a.state + prob;
+    if (a.n2cap > 0 && stp->n2 > a.n2cap) return;     // its pivoted factors were not produced (stale permutation entries)
     const int rankA = stp->rankA, n2 = stp->n2, kp = stp->kp;
     const int n = a.n, m = a.m, t = a.t, kA = a.kA, ldr = a.ldr, ldw = a.ldw;
     const double* W = a.W + prob * a.sW;

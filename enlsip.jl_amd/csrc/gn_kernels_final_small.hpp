@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
     ProbState* stp = a.state + prob;
     const int rankA = stp->rankA, n2 = stp->n2, kp = stp->kp;
     // a problem whose J2 is wider than the launch shape (rank-deficient A) is redone by the caller with the true width
-    if (kp > NR || n2 + 1 > 64 || kp * 65 > a.matd) return;
+    if (kp > NR || n2 + 1 > 64 || kp * 65 > a.matd || (a.n2cap > 0 && n2 > a.n2cap)) return;
     double* tmp = smem;
     double* vbuf = tmp + a.matd;
     double* dg = vbuf + 64;

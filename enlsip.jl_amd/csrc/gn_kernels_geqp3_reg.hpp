@@ -81,12 +81,13 @@ __global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
         double bv = -1.0;
         int bp = 0x7fffffff, bk = -1;
         if (cpos[rd][lnl] >= 0) {
-            bv = cvn1[rd][lnl];
+            bv = pivot_key(cvn1[rd][lnl]);
             bp = cpos[rd][lnl];
             bk = lnl;
         }
         const ArgMax am = wave_argmax(bv, bp, bk);
         const int ci = am.idx, q = am.pos;
+        if (ci < 0) break;                                 // no active column left (cannot happen for s < kmax; keeps every index below valid)
         if (wl == ci % NWV) {
 #pragma unroll
             for (int cc = 0; cc < NCW; ++cc) {

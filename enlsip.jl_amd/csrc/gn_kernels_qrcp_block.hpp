@@ -86,6 +86,7 @@ __global__ __launch_bounds__(1024) void k_sb_factor(SbArgs a) {
     SbLds& L = *reinterpret_cast<SbLds*>(sb_raw);
     const int prob = blockIdx.x + a.q.prob0;
     const ProbState st = a.q.state[prob];
+    if (a.q.n2cap > 0 && st.n2 > a.q.n2cap) return;      // wider than the launch shape: redone by the caller
     const int kp = st.kp, n2 = st.n2;
     SbInfo* info = a.info + prob;
     const int j0 = info->j0;
@@ -419,6 +420,7 @@ template <int RPL>
 __global__ __launch_bounds__(256) void k_sb_update(SbArgs a) {
     const int prob = blockIdx.y + a.q.prob0;
     const ProbState st = a.q.state[prob];
+    if (a.q.n2cap > 0 && st.n2 > a.q.n2cap) return;      // wider than the launch shape: redone by the caller
     const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
     const SbInfo info = a.info[prob];
     if (info.blk != a.blkid || info.s == 0) return;     // this problem did no step in this block
@@ -581,6 +583,7 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
 
     const int prob = blockIdx.y + a.q.prob0;
     const ProbState st = a.q.state[prob];
+    if (a.q.n2cap > 0 && st.n2 > a.q.n2cap) return;      // wider than the launch shape: redone by the caller
     const int kp = st.kp, n2 = st.n2, ctot = n2 + 1;
     const SbInfo info = a.info[prob];
     if (info.blk != a.blkid || info.s == 0) return;     // this problem did no step in this block

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64 * NWV) void k_sb_factor_reg(SbArgs a) {
     __shared__ SbRegLds L;
     const int prob = blockIdx.x + a.q.prob0;
     const ProbState st = a.q.state[prob];
+    if (a.q.n2cap > 0 && st.n2 > a.q.n2cap) return;      // wider than the launch shape: redone by the caller
     const int kp = st.kp, n2 = st.n2;
     SbInfo* info = a.info + prob;
     const int j0 = info->j0;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(64 * NWV) void k_sb_factor_reg(SbArgs a) {
         double bv = -1.0;
         int bp = 0x7fffffff, bk = -1;
         if (lnl < K && L.cpos[rd][lnl] >= 0) {
-            bv = L.cvn1[rd][lnl];
+            bv = pivot_key(L.cvn1[rd][lnl]);
             bp = L.cpos[rd][lnl];
             bk = lnl;
         }

@@ -42,6 +42,9 @@ struct QdArgs {
     const ProbState* state;
     // General (tall) inputs — the constraint stage with many constraints (run_constraint_dist): the matrix has `rows` rows,
     // state.n2 columns (+ one carried column) and min(rows, n2) pivot steps.  rows = 0: the R0 case, rows = steps = state.kp.
+    int n2cap;         // > 0: launch shape; a problem whose J2 turned out WIDER (rank-deficient A, state.n2 > n2cap) is skipped by
+                       // every kernel of the stage: the grids do not cover its columns, so its maps would hold stale entries of
+                       // earlier solves that the single-workgroup kernels would use as indices.  The caller redoes the batch.
     int rows;
     int in_mode;       // k_qd_init: 0 = R0 out of the CAQR storage W; 1 = dense Ain (rows x n2, ld ldain), carried column zero;
                        // 2 = lower trapezoid L[i][j] = (j <= i) ? Ain[j + i * ldain] : 0 (the transposed R of a factor),
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(256) void k_qd_init(QdArgs a) {
     __shared__ int cpos[QD_CPW];
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
+    if (a.n2cap > 0 && st.n2 > a.n2cap) return;
     const int n2 = st.n2, ctot = n2 + 1;
     const int kp = qd_rows(a, st.kp);          // rows of the matrix
     const int g = blockIdx.x;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void k_qd_init(QdArgs a) {
                 a.chosen[prob * a.sI + c] = -1;
                 a.pos[prob * 2 * a.sI + c] = c;
                 a.colat[prob * 2 * a.sI + c] = c;
-                cval[slot] = nv;
+                cval[slot] = pivot_key(nv);
                 cpos[slot] = c;
             } else {
                 cval[slot] = -1.0;
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
     __shared__ int cpos[QD_CPW];
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
+    if (a.n2cap > 0 && st.n2 > a.n2cap) return;
     const int n2 = st.n2, ctot = n2 + 1;
     const int kp = qd_rows(a, st.kp);          // rows of the matrix (= number of steps in the R0 case)
     const int j = a.step;
@@ -201,6 +206,8 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
             bc = oc;
         }
     }
+    if (bc < 0) return;        // no candidate (cannot happen while unchosen columns exist: NaN norms rank as +inf); every
+                               // workgroup takes the same decision, so nobody indexes with -1
     const int p = bc;          // physical pivot column
     const int q = bp;          // its logical position
     // (b) reflector of the pivot column (rows j..kp-1)
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
                     }
                     const int np = (c == cj) ? q : cps[u];
                     if (ln == 0) pos_new[c] = np;
-                    candv = o1;
+                    candv = pivot_key(o1);
                     candp = np;
                 }
             } else if (ln == 0) {
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
 __global__ __launch_bounds__(256) void k_qd_assemble(QdArgs a) {
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
+    if (a.n2cap > 0 && st.n2 > a.n2cap) return;
     const int n2 = st.n2, ctot = n2 + 1;
     const int kp = qd_rows(a, st.kp);
     const int nst = qd_steps(a, st.kp, n2);

@@ -39,6 +39,7 @@ struct QpArgs {
     unsigned* abort_word;                  // one word, zeroed per launch
     ProbState* state;
     int spin_limit;
+    int n2cap;             // > 0: launch shape; wider problems are skipped (see QdArgs::n2cap)
 };
 
 __device__ __forceinline__ void qp_store_f64(double* p, double v) {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void k_qrcp_persist(QpArgs a) {
     const int prob = blockIdx.y + a.prob0;
     ProbState* stp = a.state + prob;
     const int kp = stp->kp, n2 = stp->n2, rankA = stp->rankA, ctot = n2 + 1;
-    if (kp == 0) return;   // uniform over the problem's workgroups
+    if (kp == 0 || (a.n2cap > 0 && n2 > a.n2cap)) return;   // uniform over the problem's workgroups
     const int g = blockIdx.x, G = a.G, CW = a.CW, ldk = a.kp_pad;
     const int ln = lane_id(), w = wave_id(), tid = threadIdx.x;
     double* slab = qp_smem;                               // [lc * ldk + r]

@@ -44,7 +44,7 @@ __device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrc
     const double tol3z = 1.4901161193847656e-08;  // sqrt(eps), dlaqp2
     // (a) pivot = first position of the largest partial norm among the unprocessed columns
     const bool cand = (ln < q.ncand) && (mypos >= j);
-    const ArgMax am = wave_argmax(cand ? vn1 : -1.0, mypos, ln);
+    const ArgMax am = wave_argmax(cand ? pivot_key(vn1) : -1.0, mypos, ln);
     const int pl = am.idx, pp = am.pos;
     // (b) LAPACK's swap of positions j <-> pp
     if (mypos == j) mypos = pp;

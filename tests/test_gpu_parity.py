@@ -377,6 +377,32 @@ def test_factor_constraints_alone(kind, m, n, t, solver):
     assert rel(out.p, ref.p) <= 1e-9 and solver.factor(FACTOR_J2).R.shape == ref.F_J2.R.shape
 
 
+@pytest.mark.parametrize("m,n,t", [(256, 32, 4), (900, 300, 20), (4096, 512, 64), (700, 300, 100), (1300, 600, 8)])
+@pytest.mark.parametrize("kind", ["nanJ", "nanA", "zeroA", "allzero"])
+def test_nonfinite_and_degenerate_inputs_return(kind, m, n, t, solver):
+    """NaN / all-zero inputs: whatever IEEE arithmetic makes of them, every pivot search must still return one of its
+    candidates (a NaN norm ranks as +inf) — an empty search used to index with -1 and fault in k_geqp3_reg."""
+    J, rx, A, cx = synth.make_problem(5, m, n, t)
+    if kind == "nanJ":
+        J[m // 2, n // 3] = np.nan
+    elif kind == "nanA":
+        A[0, 0] = np.nan
+    elif kind == "zeroA":
+        A[:] = 0.0
+    else:
+        J[:] = 0.0; A[:] = 0.0; rx[:] = 0.0; cx[:] = 0.0
+    out = solver.solve(J, rx, A, cx)
+    assert 0 <= out.rankA <= min(n, t) and 0 <= out.rankJ2 <= min(m, n)
+    assert out.p.shape == (n,)
+    if kind == "zeroA":
+        assert out.rankA == 0 and out.code == -1 and np.all(np.isfinite(out.p))
+    if kind == "allzero":
+        assert out.rankA == 0 and out.rankJ2 == 0 and np.all(out.p == 0.0)
+    J, rx, A, cx = synth.make_problem(6, m, n, t)            # the handle is fine afterwards
+    ref = go.gn_subproblem(J, rx, A, cx)
+    assert rel(solver.solve(J, rx, A, cx).p, ref.p) <= TOL_P
+
+
 def test_argument_errors(solver):
     from enlsip_gn import GNError
     J, rx, A, cx = synth.make_problem(1, 50, 10, 2)
