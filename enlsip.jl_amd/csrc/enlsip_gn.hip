@@ -45,6 +45,16 @@ using namespace gn;
 
 static inline long long rup(long long x, long long a) { return (x + a - 1) / a * a; }
 
+#define GN_TRACE(h, ...)                                              \
+    do {                                                              \
+        if ((h)->trace) {                                             \
+            (void)hipStreamSynchronize((h)->stream);                  \
+            fprintf(stderr, "[enlsip_gn] " __VA_ARGS__);              \
+            fputc('\n', stderr);                                      \
+            fflush(stderr);                                           \
+        }                                                             \
+    } while (0)
+
 static int grow(enlsip_gn_handle h, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes) return 0;
     if (b.p) GN_HIP(hipFree(b.p));
@@ -368,6 +378,7 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     while (it < kp_launch) {
         for (int i = 0; i < chunk && it < kp_launch; ++i, ++it) {
             a.blkid = it;
+            GN_TRACE(h, "  qrcp block %d", it);
             if (big) {
                 hipLaunchKernelGGL(k_sb_factor<16>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
                 hipLaunchKernelGGL(k_sb_update<16>, ugrid, dim3(256), 0, s, a);
@@ -595,9 +606,11 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
     mark(0);
     h->constraints_only = false;
     // 1. constraint stage
+    GN_TRACE(h, "solve m=%lld n=%lld t=%lld batch=%lld: constraint stage", m, n, t, batch);
     rc = run_constraint_stage(h, batch, m, n, t, dAt, ldat, strideAt, dcx, eps_rank, dimA_ov);
     if (rc) return rc;
     mark(1);
+    GN_TRACE(h, "constraint stage done");
 
     int n2_launch = (int)(n - P.kA);  // speculate rankA = min(n, t); verified after the solve
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -614,10 +627,12 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         else if (launch_jq1_rows(qa, (int)batch, s)) {}                             // small n, few reflectors
         else if (getenv("ENLSIP_GN_JQ1_V1") || !launch_jq1_v2(qa, (int)batch, s)) launch_jq1_mfma(qa, (int)batch, s);
         mark(2);
+        GN_TRACE(h, "attempt %d n2_launch=%d: J*Q1 done", attempt, n2_launch);
         // 3. CAQR of [J2 | d]
         rc = run_caqr(h, n2_launch);
         if (rc) return rc;
         mark(3);
+        GN_TRACE(h, "CAQR done");
         // 4. pivoted QR of R0 + solves + outputs
         FinalArgs fa{};
         fa.m = (int)m; fa.n = (int)n; fa.t = (int)t; fa.kA = P.kA; fa.ldw = P.ldw; fa.ldr = P.ldr;
@@ -650,9 +665,11 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
                 fa.refactor = 2;
             }
         }
+        GN_TRACE(h, "pivoted QR of R0 done (refactor %d)", fa.refactor);
         if (!launch_pivot_small((int)std::min<long long>(m, n2_launch), n2_launch, (int)batch, s, fa))
             launch_pivot((int)std::min<long long>(m, n), (int)batch, s, fa);
         mark(4);
+        GN_TRACE(h, "final kernel done");
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
         GN_HIP(hipStreamSynchronize(s));
@@ -745,6 +762,7 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (qm && qm[0] == 's') h->qrcp_mode = 1;            // step: one launch per pivot step
         const char* fw = getenv("ENLSIP_GN_FACTOR_WAVES");   // 4 or 8 waves per panel-factor workgroup (A/B switch)
         if (fw && fw[0] == '4') h->factor_waves = 4;
+        h->trace = getenv("ENLSIP_GN_TRACE") != nullptr;
         const char* pl = getenv("ENLSIP_GN_PIPELINE");       // 0: never split a batch over two streams
         if (pl && pl[0] == '0') h->pipeline = false;
     }

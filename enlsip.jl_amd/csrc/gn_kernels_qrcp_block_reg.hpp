@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * NWV) void k_sb_factor_reg(SbArgs a) {
     // ---- 1. keys of the trailing columns --------------------------------------------------------
     for (int c = tid; c < n2; c += NT) {
         const bool tr = chosen[c] < 0;
-        L.valk[c] = tr ? vn1[c] : -1.0;
+        L.valk[c] = tr ? pivot_key(vn1[c]) : -1.0;      // NaN norms rank as +inf: the order stays total, every slot < K is filled
         const int p = pos[c];
         L.posk[c] = tr ? p : 0x7fffffff;
         L.pos_l[c] = p;
