@@ -34,9 +34,39 @@ for k in range(calls):
         ref = go.gn_subproblem(J, rx, A, cx)
         nb = np.linalg.norm(ref.p)
         ok = ok and np.linalg.norm(out.p - ref.p) <= 1e-9 * (nb if nb else 1.0)
+    if k % 3 == 0:          # the consumers of the resident factors after whatever the solve left behind (errors are fine, crashes not)
+        from enlsip_gn import FACTOR_A, FACTOR_L11, FACTOR_J2, GNError
+        try:
+            for which, ln in ((FACTOR_A, n), (FACTOR_L11, t), (FACTOR_J2, m)):
+                fv = s.factor(which)
+                R = fv.R
+                if R.shape[0]:
+                    fv.Qt_mul(np.ones(ln)); fv.Q_mul(np.ones(ln))
+            s.JQ1(m, n)
+            s.gradient(n); s.jacobian_times(m, t, out.p)
+            s.first_lagrange(t, None, None); s.second_lagrange(t, out.p, None)
+            kp = min(m, n - out.rankA)
+            s.resolve(m, n, t, int(rng.integers(0, out.rankA + 1)), int(rng.integers(0, max(min(out.rankJ2, kp), 0) + 1)), -1)
+        except GNError:
+            pass
     if not ok:
         bad += 1
         print("FAIL", kind, m, n, t, out.rankA, out.rankJ2, flush=True)
-print(f"{calls} calls, {bad} failures, {time.time() - t0:.1f} s")
+# batched calls with degenerate members
+for k in range(calls // 20):
+    n = int(rng.integers(8, 200)); m = int(rng.integers(n, 800)); t = int(rng.integers(1, min(n, 80))); B = int(rng.integers(2, 9))
+    Js, rxs, Ats, cxs = [], [], [], []
+    for b in range(B):
+        J, rx, A, cx = synth.make_problem(90000 + 16 * k + b, m, n, t)
+        kind = int(rng.integers(0, 5))
+        if kind == 1: A[:] = 0.0
+        if kind == 2: A[0, 0] = np.nan
+        if kind == 3 and t >= 2: A[1:] = A[0]
+        if kind == 4: J[0, 0] = np.nan
+        Js.append(np.ascontiguousarray(J.T)); rxs.append(rx); Ats.append(np.ascontiguousarray(A)); cxs.append(cx)
+    p, b_, d, infos, jA, jL, jJ = s.solve_batched(np.stack(Js), np.stack(rxs), np.stack(Ats), np.stack(cxs))
+    if p.shape != (B, n):
+        bad += 1
+print(f"{calls} calls (+ {calls // 20} batched), {bad} failures, {time.time() - t0:.1f} s")
 s.close()
 sys.exit(1 if bad else 0)
