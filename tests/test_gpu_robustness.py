@@ -1,0 +1,82 @@
+"""Robustness of the HIP path (GPU): one handle reused across random shapes with degenerate / non-finite inputs (two GPU memory
+faults were found this way, profiles/r1_notes.md), and padded leading dimensions / strides on the device entry.  Longer versions:
+tests/stress_reuse.py, tests/ld_padding.py, tests/stress_pipelined.py, tests/stress_tsqr.py."""
+import numpy as np
+import pytest
+
+from oracle import gn_oracle as go, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / (nb if nb > 0 else 1.0))
+
+
+@pytest.mark.parametrize("seed", [3, 11])
+def test_handle_reuse_with_degenerate_inputs(seed):
+    from enlsip_gn import GNSolver, GNError, FACTOR_A, FACTOR_L11, FACTOR_J2
+    rng = np.random.default_rng(seed)
+    s = GNSolver(device=0)
+    try:
+        for k in range(90):
+            cls = rng.integers(0, 4)
+            if cls == 0: n = int(rng.integers(4, 65)); m = int(rng.integers(n, 600)); t = int(rng.integers(1, min(n, 60) + 1))
+            elif cls == 1: n = int(rng.integers(65, 320)); m = int(rng.integers(n, 1500)); t = int(rng.integers(1, 64))
+            elif cls == 2: n = int(rng.integers(320, 700)); m = int(rng.integers(300, 1600)); t = int(rng.integers(1, 64))
+            else: n = int(rng.integers(100, 400)); m = int(rng.integers(n, 1200)); t = int(rng.integers(65, min(n, 200)))
+            kind = ["full", "rankdefA", "zeroA", "nanA", "dupA", "nanJ", "infJ", "zeroJ"][int(rng.integers(0, 8))]
+            J, rx, A, cx = (synth.make_rank_deficient_A if (kind == "rankdefA" and t >= 2) else synth.make_problem)(81000 + k, m, n, t)
+            if kind == "zeroA": A[:] = 0.0
+            if kind == "nanA": A[int(rng.integers(0, t)), int(rng.integers(0, n))] = np.nan
+            if kind == "dupA" and t >= 3: A[1:] = A[0]
+            if kind == "nanJ": J[int(rng.integers(0, m)), int(rng.integers(0, n))] = np.nan
+            if kind == "infJ": J[int(rng.integers(0, m)), int(rng.integers(0, n))] = np.inf
+            if kind == "zeroJ": J[:] = 0.0
+            out = s.solve(J, rx, A, cx)
+            assert out.p.shape == (n,) and 0 <= out.rankA <= min(n, t)
+            if kind == "full" and k % 3 == 0:
+                assert rel(out.p, go.gn_subproblem(J, rx, A, cx).p) <= 1e-9
+            if k % 4 == 0:      # consumers of whatever the solve left resident: errors are fine, faults are not
+                try:
+                    for which, ln in ((FACTOR_A, n), (FACTOR_L11, t), (FACTOR_J2, m)):
+                        fv = s.factor(which)
+                        if fv.R.shape[0]:
+                            fv.Qt_mul(np.ones(ln))
+                    s.JQ1(m, n); s.gradient(n); s.first_lagrange(t, None, None); s.second_lagrange(t, out.p, None)
+                    s.resolve(m, n, t, int(rng.integers(0, out.rankA + 1)), 0, -1)
+                except GNError:
+                    pass
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("B,m,n,t,pj,pa", [(2, 4096, 512, 64, 7, 3), (4, 256, 32, 4, 5, 1), (2, 700, 300, 100, 9, 2), (130, 300, 40, 6, 3, 1)])
+def test_padded_leading_dimensions_and_strides(B, m, n, t, pj, pa):
+    import torch
+    from enlsip_gn import GNSolver, SQRT_EPS
+    dev = torch.device("cuda", 0)
+    ldj, ldat = m + pj, n + pa
+    sJ, sAt = ldj * n + 11, ldat * t + 5
+    probs = [synth.make_problem(98000 + k, m, n, t) for k in range(B)]
+    Jbuf = torch.full((B * sJ,), float("nan"), dtype=torch.float64, device=dev)      # NaN in every gap: never to be read as data
+    Abuf = torch.full((B * sAt,), float("nan"), dtype=torch.float64, device=dev)
+    for k, (J, rx, A, cx) in enumerate(probs):
+        Jp = np.full((n, ldj), np.nan); Jp[:, :m] = J.T
+        Jbuf[k * sJ: k * sJ + ldj * n] = torch.tensor(Jp.ravel(), device=dev)
+        Ap = np.full((t, ldat), np.nan); Ap[:, :n] = A
+        Abuf[k * sAt: k * sAt + ldat * t] = torch.tensor(Ap.ravel(), device=dev)
+    rx = torch.tensor(np.stack([p[1] for p in probs]), dtype=torch.float64, device=dev)
+    cx = torch.tensor(np.stack([p[3] for p in probs]), dtype=torch.float64, device=dev)
+    pout = torch.empty((B, n), dtype=torch.float64, device=dev)
+    s = GNSolver(device=0)
+    try:
+        s.solve_batched_dev(B, m, n, t, Jbuf.data_ptr(), ldj, sJ, rx.data_ptr(), Abuf.data_ptr(), ldat, sAt, cx.data_ptr(), SQRT_EPS,
+                            dp=pout.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        s.close()
+    P = pout.cpu().numpy()
+    for k in (0, B - 1):
+        assert rel(P[k], go.gn_subproblem(*probs[k]).p) <= 1e-10
