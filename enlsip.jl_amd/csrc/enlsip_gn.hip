@@ -578,6 +578,8 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
                      double* dp, double* db, double* dd, enlsip_gn_info* dinfo,
                      long long* djA, long long* djL, long long* djJ) {
     h->split = 0;   // routing of accessors to the pipeline child is (re)established by the batched entry point
+    const bool reuse = h->reuse_once;
+    h->reuse_once = false;
     int rc = check_limits(h, batch, m, n, t);
     if (rc) return rc;
     if (ldj < m) { h->err = "ldj < m"; return -7; }
@@ -606,9 +608,11 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
     mark(0);
     h->constraints_only = false;
     // 1. constraint stage
-    GN_TRACE(h, "solve m=%lld n=%lld t=%lld batch=%lld: constraint stage", m, n, t, batch);
-    rc = run_constraint_stage(h, batch, m, n, t, dAt, ldat, strideAt, dcx, eps_rank, dimA_ov);
-    if (rc) return rc;
+    GN_TRACE(h, "solve m=%lld n=%lld t=%lld batch=%lld: constraint stage%s", m, n, t, batch, reuse ? " (resident)" : "");
+    if (!reuse) {       // enlsip_gn_solve_factored: F_A, F_L11, b, p1, T and the state record are those of enlsip_gn_factor_constraints
+        rc = run_constraint_stage(h, batch, m, n, t, dAt, ldat, strideAt, dcx, eps_rank, dimA_ov);
+        if (rc) return rc;
+    }
     mark(1);
     GN_TRACE(h, "constraint stage done");
 
@@ -901,15 +905,24 @@ int enlsip_gn_solve_batched_dev(enlsip_gn_handle h, int64_t batch, int64_t m, in
 static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t, const double* J,
                       int64_t ldj, int64_t strideJ, const double* rx, const double* At, int64_t ldat,
                       int64_t strideAt, const double* cx, double eps_rank, int64_t dimA_ov, int64_t dimJ2_ov,
-                      double* p, double* b, double* d, enlsip_gn_info* info, int64_t* jA, int64_t* jL, int64_t* jJ) {
+                      double* p, double* b, double* d, enlsip_gn_info* info, int64_t* jA, int64_t* jL, int64_t* jJ,
+                      bool factored = false) {
     if (!h) return -1;
     int rc = check_limits(h, batch, m, n, t);
     if (rc) return rc;
     if (!J) return -6;
     if (ldj < m) return -7;
     if (!rx) return -9;
-    if (t > 0 && (!At || !cx)) return -10;
-    if (t > 0 && ldat < n) return -11;
+    if (factored) {
+        const Plan& P = h->plan;
+        if (!(h->factors_valid && h->constraints_only && h->have_plan && P.batch == 1 && P.m == m && P.n == n && P.t == t)) {
+            h->err = "enlsip_gn_solve_factored needs enlsip_gn_factor_constraints with the same m, n, t right before";
+            return -1;
+        }
+    } else {
+        if (t > 0 && (!At || !cx)) return -10;
+        if (t > 0 && ldat < n) return -11;
+    }
     GN_HIP(hipSetDevice(h->device));
     const int kA = (int)std::min(n, t);
     // staging: inputs packed (ld = m / n), outputs packed
@@ -935,12 +948,13 @@ static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, i
     for (int64_t k = 0; k < batch; ++k) {
         GN_HIP(hipMemcpy2DAsync(dJ + (size_t)k * m * n, (size_t)m * 8, J + (size_t)k * strideJ, (size_t)ldj * 8,
                                 (size_t)m * 8, (size_t)n, hipMemcpyHostToDevice, s));
-        if (t > 0)
+        if (t > 0 && !factored)
             GN_HIP(hipMemcpy2DAsync(dAt + (size_t)k * n * t, (size_t)n * 8, At + (size_t)k * strideAt,
                                     (size_t)ldat * 8, (size_t)n * 8, (size_t)t, hipMemcpyHostToDevice, s));
     }
     GN_HIP(hipMemcpyAsync(drx, rx, (size_t)batch * m * 8, hipMemcpyHostToDevice, s));
-    if (t > 0) GN_HIP(hipMemcpyAsync(dcx, cx, (size_t)batch * t * 8, hipMemcpyHostToDevice, s));
+    if (t > 0 && !factored) GN_HIP(hipMemcpyAsync(dcx, cx, (size_t)batch * t * 8, hipMemcpyHostToDevice, s));
+    h->reuse_once = factored;      // A', cx (same staging slots) and the constraint factors are resident
     rc = solve_dev(h, batch, m, n, t, dJ, m, m * n, drx, dAt, n, n * t, dcx, eps_rank, dimA_ov, dimJ2_ov, dp, db, dd,
                    nullptr, djA, djL, djJ);
     if (rc) return rc;
@@ -997,6 +1011,13 @@ int enlsip_gn_factor_constraints(enlsip_gn_handle h, int64_t m, int64_t n, int64
         *info = {st.rankA, 0, st.code, st.dimA, 0, st.status};
     }
     return 0;
+}
+
+int enlsip_gn_solve_factored(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const double* J, int64_t ldj,
+                             const double* rx, double eps_rank, int64_t dimJ2_override, double* p, double* b, double* d,
+                             enlsip_gn_info* info, int64_t* jpvtA, int64_t* jpvtL, int64_t* jpvtJ2) {
+    return solve_host(h, 1, m, n, t, J, ldj, (int64_t)ldj * n, rx, nullptr, n, (int64_t)n * t, nullptr, eps_rank, -1,
+                      dimJ2_override, p, b, d, info, jpvtA, jpvtL, jpvtJ2, true);
 }
 
 int enlsip_gn_solve_batched(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t, const double* J,

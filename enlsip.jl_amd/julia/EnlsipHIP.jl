@@ -238,6 +238,27 @@ function factor_constraints_hip!(h::Handle, m::Integer, A::Matrix{Float64}, cx::
     return info[].rankA, DeviceQR(h, FACTOR_A, n), DeviceQR(h, FACTOR_L11, t)
 end
 
+"""    gn_search_direction_factored_hip!(h, J, rx, t, ε_rank, iter_k) -> (p_gn, F_A, F_L11, F_J2)
+
+The solve of `update_working_set`'s `s == 0` branch (:768-771) right after `factor_constraints_hip!` with the same working set:
+the resident `F_A`, `F_L11`, `b`, `p1` are reused, only `J` and `rx` are sent.
+"""
+function gn_search_direction_factored_hip!(h::Handle, J::Matrix{Float64}, rx::Vector{Float64}, t::Integer, ε_rank::Float64, iter_k)
+    m, n = size(J)
+    kA = min(n, t)
+    p = zeros(Float64, n); b = zeros(Float64, max(t, 1)); d = zeros(Float64, m)
+    jA = zeros(Int64, max(t, 1)); jL = zeros(Int64, max(kA, 1)); jJ = zeros(Int64, n)
+    info = Ref(Info(0, 0, 0, 0, 0, 0))
+    GC.@preserve J rx p b d jA jL jJ check(h, ccall((:enlsip_gn_solve_factored, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Float64, Int64, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ref{Info}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+        h.ptr, m, n, t, J, m, rx, ε_rank, -1, p, b, d, info, jA, jL, jJ))
+    iter_k.rankA = info[].rankA; iter_k.rankJ2 = info[].rankJ2
+    iter_k.dimA = info[].dimA; iter_k.dimJ2 = info[].dimJ2
+    iter_k.b_gn = b[1:t]; iter_k.d_gn = d
+    return p, DeviceQR(h, FACTOR_A, n), DeviceQR(h, FACTOR_L11, t), DeviceQR(h, FACTOR_J2, m)
+end
+
 """    jacobian_times_hip(h, p, m, t) -> (J*p, C.A*p) on the J and A of the last solve (src/enlsip_functions.jl:2226-2229)"""
 function jacobian_times_hip(h::Handle, p::Vector{Float64}, m::Integer, t::Integer)
     Jp = zeros(Float64, m); Ap = zeros(Float64, t)

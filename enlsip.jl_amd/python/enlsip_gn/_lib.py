@@ -44,6 +44,9 @@ PROTOTYPES = {
                                   C.POINTER(Info), C.c_void_p, C.c_void_p, C.c_void_p]),
     "enlsip_gn_factor_constraints": (C.c_int, [_h, _i64, _i64, _i64, C.c_void_p, _i64, C.c_void_p, C.c_double,
                                                C.POINTER(Info)]),
+    "enlsip_gn_solve_factored": (C.c_int, [_h, _i64, _i64, _i64, C.c_void_p, _i64, C.c_void_p, C.c_double, _i64,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Info), C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "enlsip_gn_solve_batched": (C.c_int, [_h, _i64, _i64, _i64, _i64, C.c_void_p, _i64, _i64, C.c_void_p,
                                           C.c_void_p, _i64, _i64, C.c_void_p, C.c_double, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -155,6 +155,22 @@ class GNSolver:
                                                          _fptr(cxv) if t else None, eps_rank, C.byref(info)))
         return int(info.rankA), int(info.code), int(info.dimA)
 
+    def solve_factored(self, J: np.ndarray, rx: np.ndarray, t: int, eps_rank: float = SQRT_EPS, dimJ2: int = -1) -> GNResult:
+        """The solve right after factor_constraints with an unchanged working set (src/enlsip_functions.jl:768-771 reuses the
+        F_A of :700): only J and rx go in."""
+        J = np.asfortranarray(J, dtype=np.float64)
+        m, n = J.shape
+        rx = np.ascontiguousarray(rx, dtype=np.float64)
+        kA = min(n, t)
+        p, b, d = np.zeros(n), np.zeros(t), np.zeros(m)
+        jA, jL, jJ = np.zeros(t, np.int64), np.zeros(kA, np.int64), np.zeros(n, np.int64)
+        info = L.Info()
+        self._chk(self._lib.enlsip_gn_solve_factored(self._h, m, n, t, _fptr(J), m, _fptr(rx), eps_rank, dimJ2,
+                                                     _fptr(p), _fptr(b), _fptr(d), C.byref(info), _fptr(jA), _fptr(jL), _fptr(jJ)))
+        n2 = n - int(info.rankA)
+        return GNResult(p, b, d, int(info.rankA), int(info.rankJ2), int(info.code), int(info.dimA),
+                        int(info.dimJ2), int(info.status), jA, jL, jJ[:n2].copy())
+
     def solve_batched(self, J: np.ndarray, rx: np.ndarray, At: np.ndarray, cx: np.ndarray,
                       eps_rank: float = SQRT_EPS):
         """J: (batch, n, m) C-order array holding each m x n problem column-major (i.e. J[k].T is

@@ -167,9 +167,10 @@ def update_working_set(solver: GNSolver, W: WorkingSet, rx, A, C: Constraint, gr
     """Returns (F_A, F_L11, F_J2) as device-backed views, valid until the next solve on ``solver``."""
     m, n = J.shape
 
-    def _direction():
-        # F_A = qr(C.A'); rankA; F_L11 = qr(F_A.R'); p_gn, F_J2 = gn_search_direction(...)  -> one device solve
-        out = solver.solve(J, rx, C.A, C.cx, eps_rank)
+    def _direction(factored=False):
+        # F_A = qr(C.A'); rankA; F_L11 = qr(F_A.R'); p_gn, F_J2 = gn_search_direction(...)  -> one device solve;
+        # factored: the working set is the one just factored at :700, the solve goes on with that factorisation (:768-771)
+        out = solver.solve_factored(J, rx, C.A.shape[0], eps_rank) if factored else solver.solve(J, rx, C.A, C.cx, eps_rank)
         p_gn[:] = out.p
         it.rankA, it.rankJ2 = out.rankA, out.rankJ2
         it.dimA, it.dimJ2 = out.rankA, out.rankJ2
@@ -232,7 +233,7 @@ def update_working_set(solver: GNSolver, W: WorkingSet, rx, A, C: Constraint, gr
             rankA = _direction()
             rankA, lam = _second_order(rankA, lam)
     else:                                                              # :767-791
-        rankA = _direction()
+        rankA = _direction(factored=True)
         rankA, lam = _second_order(rankA, lam)
     it.lam = lam
     return _views()

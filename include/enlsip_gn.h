@@ -114,6 +114,16 @@ int enlsip_gn_factor_constraints(enlsip_gn_handle h, int64_t m, int64_t n, int64
                                  const double* cx, double eps_rank, enlsip_gn_info* info);
 
 /*
+ * The solve that follows enlsip_gn_factor_constraints when the working set did not change: update_working_set factors C.A' once
+ * (src/enlsip_functions.jl:700) and, in its s == 0 branch, goes on with that SAME factorisation (:768-771: rankA, F_L11,
+ * gn_search_direction).  Same m, n, t as the enlsip_gn_factor_constraints call right before; F_A, F_L11, b, p1 stay as they are,
+ * only J and rx are taken in.  Outputs as enlsip_gn_solve.
+ */
+int enlsip_gn_solve_factored(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const double* J, int64_t ldj,
+                             const double* rx, double eps_rank, int64_t dimJ2_override, double* p, double* b, double* d,
+                             enlsip_gn_info* info, int64_t* jpvtA, int64_t* jpvtL, int64_t* jpvtJ2);
+
+/*
  * Batch of independent subproblems of one shape, host buffers.  Problem k uses
  * J + k*strideJ, rx + k*m, At + k*strideAt, cx + k*t; outputs p + k*n, b + k*t, d + k*m,
  * info[k], jpvtA + k*t, jpvtL + k*min(n,t), jpvtJ2 + k*n.

@@ -373,8 +373,14 @@ def test_factor_constraints_alone(kind, m, n, t, solver):
         solver.second_lagrange(t, ref.p, None)
     with pytest.raises(GNError):
         solver.resolve(m, n, t, ref.rankA, ref.rankJ2, -1)
-    out = solver.solve(J, rx, A, cx)                      # a solve afterwards restores the full state
-    assert rel(out.p, ref.p) <= 1e-9 and solver.factor(FACTOR_J2).R.shape == ref.F_J2.R.shape
+    out = solver.solve_factored(J, rx, t)                 # :768-771: the solve goes on with the SAME factorisation
+    assert (out.rankA, out.rankJ2, out.code) == (ref.rankA, ref.rankJ2, ref.code)
+    assert rel(out.p, ref.p) <= 1e-9 and np.array_equal(out.jpvtA, ref.jpvtA)
+    assert solver.factor(FACTOR_J2).R.shape == ref.F_J2.R.shape
+    with pytest.raises(GNError):
+        solver.solve_factored(J, rx, t)                   # no factor_constraints right before
+    out = solver.solve(J, rx, A, cx)                      # the ordinary solve is unaffected
+    assert rel(out.p, ref.p) <= 1e-9
 
 
 @pytest.mark.parametrize("m,n,t", [(256, 32, 4), (900, 300, 20), (4096, 512, 64), (700, 300, 100), (1300, 600, 8)])
