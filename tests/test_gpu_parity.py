@@ -409,6 +409,34 @@ def test_nonfinite_and_degenerate_inputs_return(kind, m, n, t, solver):
     assert rel(solver.solve(J, rx, A, cx).p, ref.p) <= TOL_P
 
 
+@pytest.mark.parametrize("m,n,t", [(300, 40, 5), (1200, 280, 30), (512, 64, 8), (700, 300, 100)])
+@pytest.mark.parametrize("eps_rank", [1e-3, 1e-6, 1e-12])
+def test_eps_rank_drives_the_ranks(eps_rank, m, n, t, solver):
+    """pseudo_rank (src/enlsip_functions.jl:17-31) with other thresholds on a graded spectrum: ranks and p follow the oracle."""
+    J, rx, A, cx = synth.make_graded_J(7100 + m + n, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx, eps_rank)
+    out = solver.solve(J, rx, A, cx, eps_rank=eps_rank)
+    assert (out.rankA, out.code) == (ref.rankA, ref.code)
+    assert abs(out.rankJ2 - ref.rankJ2) <= 1          # a diagonal entry within rounding of the threshold may fall either side
+    if out.rankJ2 == ref.rankJ2:
+        assert rel(out.p, ref.p) <= 1e-4              # cond up to 1 / eps_rank
+
+
+@pytest.mark.parametrize("m,n,t", [(600, 40, 6), (900, 300, 20), (700, 300, 100)])
+def test_solve_with_dimension_overrides(m, n, t, solver):
+    """enlsip_gn_solve with dimA / dimJ2 below the ranks (the subspace-minimisation dimensions of
+    src/enlsip_functions.jl:1118-1176) against sub_search_direction of the oracle with the same dimensions."""
+    J, rx, A, cx = synth.make_problem(7300 + m + n, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    JQ1 = ref.F_A.rmul_Q(J)
+    for dimA, dimJ2 in ((t, ref.rankJ2 - 3), (t - 2, ref.rankJ2 // 2), (0, 1)):
+        p_ref, b_ref, d_ref = go.sub_search_direction(JQ1[:, :ref.rankA], rx, cx, ref.F_A, ref.F_L11, ref.F_J2,
+                                                      n, t, ref.rankA, dimA, dimJ2, ref.code)
+        out = solver.solve(J, rx, A, cx, dimA=dimA, dimJ2=dimJ2)
+        assert (out.rankA, out.rankJ2, out.dimA, out.dimJ2) == (ref.rankA, ref.rankJ2, dimA, dimJ2)
+        assert rel(out.p, p_ref) <= 1e-10             # (code 1 ignores dimA in both: full triangular solve, :131-133)
+
+
 def test_argument_errors(solver):
     from enlsip_gn import GNError
     J, rx, A, cx = synth.make_problem(1, 50, 10, 2)
