@@ -17,6 +17,10 @@ Extra objects on the JSON line:
   roofline      dominant kernel = level-0 CAQR trailing update (k_caqr_update_v4): algorithmic
                 bytes 8(2 m_k n_k + m_k b + b^2) per launch / launch time measured
                 with HIP events on the library's stream (enlsip_gn_get_update_stats).
+                Shapes without a level-0 update (--m 256 --n 32 ..., the C3 / C5 small-problem
+                configs) report the whole solve against the HBM stream of its operands instead.
+  whole_solve   SURVEY §8d's per-solve algorithmic bytes and flops x this GPU's solve rate
+                (GB/s and f64 TFLOP/s of the whole pipeline, context for `value`).
   cpu_baseline  the same LAPACK call sequence the Julia reference dispatches to (scipy/OpenBLAS
                 "port", oracle/cpu_baseline.py) timed on this box's host cores on a bounded sample.
 """
@@ -185,6 +189,32 @@ def main() -> int:
                     roofline["traffic"] = rec["hbm_bytes_per_launch_avg"]
                     roofline["traffic_source"] = "profiles/r1e_update_traffic_pmc.json"
 
+    # whole-solve figures from SURVEY section 8(d)'s per-solve formulas (full rank, n2 = n - t): every operand crosses HBM
+    # once per direction; flops of the LAPACK sequence the path replaces
+    n2 = n - min(n, t)
+    solve_bytes = 8.0 * (2 * m * n + 2 * m + 2 * n * t + t + n)
+    solve_flops = (2.0 * t * t * (n - t / 3.0) + (4.0 / 3.0) * t ** 3 + 4.0 * m * t * (n - t / 2.0)
+                   + 2.0 * n2 * n2 * (m - n2 / 3.0) + 2.0 * m * t + (4.0 * m * n2 - 2.0 * n2 * n2) + n2 * n2 + t * t + 4.0 * n * t)
+    sps_rank = B * args.steps / elapsed                    # this GPU's rate (weak scaling: same work per rank)
+    whole = {"bytes_per_solve": solve_bytes, "flops_per_solve": solve_flops,
+             "hbm_GBps": round(sps_rank * solve_bytes / 1e9, 1), "hbm_frac": round(sps_rank * solve_bytes / 1e9 / HBM_PEAK_GBS, 4),
+             "f64_TFLOPs": round(sps_rank * solve_flops / 1e12, 2), "f64_frac_of_78.6": round(sps_rank * solve_flops / 78.6e12, 4)}
+    if rank == 0 and not args.no_roofline and roofline is None:
+        # no level-0 trailing update at this shape (n2 <= 32: the single-panel / wave-per-problem pipeline): the bound of
+        # the whole solve is the HBM stream of its operands (batched small-problem configs)
+        roofline = {"bound": "hbm", "kernel": "whole solve (constraint + J Q1 + panel + pivoted solve kernels)",
+                    "achieved": whole["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": whole["hbm_frac"],
+                    "traffic": None, "algorithmic_bytes_per_solve": solve_bytes}
+
+    if (m, n, t) == (4096, 512, 64):
+        wl = "C2: batch of independent dense CNLS subproblems, m=4096 n=512 t=64 fp64, inputs resident in HBM"
+    elif (m, n) == (512, 64):
+        wl = f"C3: batch of independent (m=512, n=64, t={t}) subproblems fp64, inputs resident in HBM"
+    elif (m, n) == (256, 32):
+        wl = f"C5: batch of independent (m=256, n=32, t={t}) subproblems fp64, inputs resident in HBM"
+    else:
+        wl = f"custom: batch of independent (m={m}, n={n}, t={t}) subproblems fp64, inputs resident in HBM"
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:      # the CPU leg runs at N = 1 only
         from oracle import cpu_baseline as cb      # measurement leg only
@@ -203,12 +233,12 @@ def main() -> int:
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "C2: batch of independent dense CNLS subproblems, m=4096 n=512 t=64 fp64, "
-                                   "inputs resident in HBM", "m": m, "n": n, "t": t,
+            "config": {"workload": wl, "m": m, "n": n, "t": t,
                        "batch_per_gpu": B, "streams_per_gpu": S, "parallelism": f"independent subproblems x{world}"},
             "single_problem_latency_ms": round(lat_ms, 3),
             "results_check": {"finite": ok, "max_constraint_residual_problem0": cons},
             "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_step": stage_ms,
+            "whole_solve": whole,
         }
         print(json.dumps(out), flush=True)
     solver.close()

@@ -383,6 +383,21 @@ def test_factor_constraints_alone(kind, m, n, t, solver):
     assert rel(out.p, ref.p) <= 1e-9
 
 
+@pytest.mark.parametrize("m,n,t", [(50, 10, 0), (1, 1, 0), (5, 1, 1), (2000, 600, 0), (3, 3, 3), (2, 4, 4), (700, 300, 300)])
+def test_factored_flow_edge_shapes(m, n, t, solver):
+    """factor_constraints -> first_lagrange -> solve_factored at the corners of the shape space: no constraints (t = 0),
+    a single unknown, and a fully determined direction (t = n, rankJ2 = 0)."""
+    J, rx, A, cx = synth.make_problem(123 + m + n + t, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    rankA, code, dimA = solver.factor_constraints(m, A, cx)
+    assert (rankA, code) == (ref.rankA, ref.code)
+    lam, gres = solver.first_lagrange(t, J.T @ rx, None)
+    assert lam.shape == (t,) and np.isfinite(gres)
+    out = solver.solve_factored(J, rx, t)
+    assert (out.rankA, out.rankJ2) == (ref.rankA, ref.rankJ2)
+    assert rel(out.p, ref.p) <= 1e-10
+
+
 @pytest.mark.parametrize("m,n,t", [(256, 32, 4), (900, 300, 20), (4096, 512, 64), (700, 300, 100), (1300, 600, 8)])
 @pytest.mark.parametrize("kind", ["nanJ", "nanA", "zeroA", "allzero"])
 def test_nonfinite_and_degenerate_inputs_return(kind, m, n, t, solver):
