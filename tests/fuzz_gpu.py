@@ -79,6 +79,44 @@ def main():
                 ok = ok and rel(lam, lam_ref) <= 1e-8
             if not ok:
                 print("  (accessor / resolve / multiplier stage)")
+        if ok and (k % 4 == 1) and not (kind == "rankdefA" and m < n - ref.rankA):
+            # the update_working_set sequence: constraint stage alone, first estimate, the solve that goes on with it;
+            # then the second estimate and the line-search products on the resident data (any kind, any size)
+            try:
+                rA, code, dimA = s.factor_constraints(m, A, cx)
+                ok2 = (rA, code) == (ref.rankA, ref.code)
+                g = J.T @ rx
+                if t:
+                    it = go.IterationRecord()
+                    lam_ref = go.first_lagrange_mult_estimate(A, g, cx, False, np.ones(t), ref.F_A, it, go.SQRT_EPS)
+                    lam, gres = s.first_lagrange(t, g, None)
+                    if kind == "full":
+                        ok2 = ok2 and rel(lam, lam_ref) <= 1e-8 and abs(gres - it.grad_res) <= 1e-8 * max(1.0, abs(it.grad_res))
+                    else:
+                        ok2 = ok2 and np.all(np.isfinite(lam))
+                o2 = s.solve_factored(J, rx, t)
+                if not ok2: print("   first estimate / ranks")
+                ok2 = ok2 and (o2.rankA, o2.code) == (ref.rankA, ref.code) and rel(o2.p, out.p) <= 1e-12
+                if not ok2: print(f"   solve_factored vs solve: rel {rel(o2.p, out.p):.2e}")
+                Jp, Ap = s.jacobian_times(m, t, o2.p)
+                jp_bound = 1e-13 * max(n, 8) * float((np.abs(J) @ np.abs(o2.p)).max() + 1e-300)
+                ok2 = ok2 and np.abs(Jp - J @ o2.p).max() <= jp_bound and (t == 0 or np.abs(Ap - A @ o2.p).max() <= 1e-13 * max(n, 8) * float((np.abs(A) @ np.abs(o2.p)).max() + 1e-300))
+                if not ok2: print("   jacobian_times")
+                if t and kind == "full":
+                    lam2_ref = go.second_lagrange_mult_estimate(J, ref.F_A, rx, ref.p, t, False, np.ones(t))
+                    lam2 = s.second_lagrange(t, o2.p, None)
+                    # J1'(rx + J p) is pure rounding when J2 is underdetermined (zero residual): absolute scale of the estimate
+                    dR = np.abs(np.diag(ref.F_A.R))
+                    scale2 = np.linalg.norm(lam2_ref) + np.linalg.norm(J) * (np.linalg.norm(rx) + np.linalg.norm(J) * np.linalg.norm(ref.p)) / dR.min()
+                    e2 = float(np.linalg.norm(lam2 - lam2_ref))
+                    if not (e2 <= 1e-9 * scale2): print(f"   second estimate abs {e2:.2e} scale {scale2:.2e}")
+                    ok2 = ok2 and e2 <= 1e-9 * scale2
+            except Exception as e:
+                ok2 = False
+                print(f"  exception in the factored flow: {type(e).__name__}: {e}")
+            if not ok2:
+                ok = False
+                print("  (factor_constraints / solve_factored / estimates stage)")
         if not ok:
             bad += 1
             print(f"FAIL {kind} m={m} n={n} t={t}: ranks hip ({out.rankA},{out.rankJ2},{out.code}) ref ({ref.rankA},{ref.rankJ2},{ref.code}) "
