@@ -1,0 +1,74 @@
+"""Hock-Schittkowski least-squares problems (tests/hs_problems.py; data and solutions from the published collection, the
+reference itself ships only HS65) through the restated outer iteration: the oracle backend must reach the published solutions,
+and — on a GPU — the HIP library plugged in at the update_working_set seam must follow the oracle run iteration for iteration
+(same working sets, ranks, codes, objective values and step lengths)."""
+import math
+
+import numpy as np
+import pytest
+
+import hs_problems as hp
+
+# hs27 ends in the reference algorithm's "more than five Newton steps" exit (-9) away from the published point: kept for the
+# iteration-for-iteration comparison (it walks the Newton and failure branches), excluded from the known-answer check
+CONVERGING = [k for k in hp.PROBLEMS if k != "hs27"]
+_cache = {}
+
+
+def _oracle_run(name):
+    from oracle import enlsip_outer as eo
+    if name not in _cache:
+        _cache[name] = hp.run(name, eo.OracleBackend())
+    return _cache[name]
+
+
+@pytest.mark.parametrize("name", CONVERGING)
+def test_hs_oracle_backend_reaches_the_published_solution(name):
+    P = hp.PROBLEMS[name]()
+    res = _oracle_run(name)
+    assert math.isfinite(res.f)
+    assert abs(res.f - P["f_star"]) <= 1e-7 * max(1.0, abs(P["f_star"]))
+    assert np.abs(res.x - P["x_star"]).max() <= 2e-6 * max(1.0, np.abs(P["x_star"]).max())     # solutions published to 7 digits
+    if "eq" in P:
+        assert np.abs(P["eq"](res.x)).max() <= 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(hp.PROBLEMS))
+def test_hs_hip_backend_iteration_for_iteration(name):
+    """Every iteration whose direction is above rounding level must agree: working set size, ranks, code, objective, step length.
+    Two things are noise in BOTH runs and are not compared: (1) at the converged point the direction is rounding
+    (|p| <= 1e-8 max(1, |x|)), so the step length, a degenerate multiplier's sign (working set) and which convergence criteria
+    fire (the exit sub-code) are decided by the last bits; (2) after the first Newton iteration (code 2: finite-difference
+    Hessians, hs27 only) differences of 1e-12 grow by orders of magnitude per step — there the sequence of codes, working sets and
+    ranks is still compared, the values only loosely."""
+    from enlsip_gn import GNSolver
+    from hip_backend import HipBackend
+    ref = _oracle_run(name)
+    s = GNSolver(device=0)
+    res = hp.run(name, HipBackend(s))
+    s.close()
+    assert res.iterations == ref.iterations
+    xs = max(1.0, float(np.abs(ref.x).max()))
+    newton = False
+    last_noise = False
+    compared = 0
+    for a, b in zip(res.trace, ref.trace):
+        last_noise = max(a["pnorm"], b["pnorm"]) <= 1e-8 * xs
+        newton = newton or b["code"] == 2
+        if not newton:
+            assert abs(a["f"] - b["f"]) <= 1e-8 * max(1.0, abs(b["f"]))
+        if last_noise:
+            continue
+        assert (a["code"], a["t"], a["rankA"], a["rankJ2"]) == (b["code"], b["t"], b["rankA"], b["rankJ2"])
+        if not newton:
+            assert abs(a["alpha"] - b["alpha"]) <= 1e-6 * max(1.0, abs(b["alpha"]))
+            assert abs(a["pnorm"] - b["pnorm"]) <= 1e-6 * max(1.0, abs(b["pnorm"]))
+            compared += 1
+    assert compared >= 1
+    if last_noise:
+        assert (res.exit_code > 0) == (ref.exit_code > 0) or abs(res.f - ref.f) <= 1e-9 * max(1.0, abs(ref.f))
+    else:
+        assert res.exit_code == ref.exit_code
+    if not newton:
+        assert np.abs(res.x - ref.x).max() <= 1e-7 * xs
