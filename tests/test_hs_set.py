@@ -9,9 +9,9 @@ import pytest
 
 import hs_problems as hp
 
-# hs27 ends in the reference algorithm's "more than five Newton steps" exit (-9) away from the published point: kept for the
-# iteration-for-iteration comparison (it walks the Newton and failure branches), excluded from the known-answer check
-CONVERGING = [k for k in hp.PROBLEMS if k != "hs27"]
+# hp.NO_KNOWN_ANSWER: runs that end away from the published point (e.g. hs27 in the algorithm's "more than five Newton steps"
+# exit -9): kept for the iteration-for-iteration comparison (they walk the Newton and failure branches)
+CONVERGING = [k for k in hp.PROBLEMS if k not in hp.NO_KNOWN_ANSWER]
 _cache = {}
 
 
@@ -28,7 +28,8 @@ def test_hs_oracle_backend_reaches_the_published_solution(name):
     res = _oracle_run(name)
     assert math.isfinite(res.f)
     assert abs(res.f - P["f_star"]) <= 1e-7 * max(1.0, abs(P["f_star"]))
-    assert np.abs(res.x - P["x_star"]).max() <= 2e-6 * max(1.0, np.abs(P["x_star"]).max())     # solutions published to 7 digits
+    x_tol = hp.X_TOL.get(name, 2e-6)                                       # solutions published to 7 digits
+    assert np.abs(res.x - P["x_star"]).max() <= x_tol * max(1.0, np.abs(P["x_star"]).max())
     if "eq" in P:
         assert np.abs(P["eq"](res.x)).max() <= 1e-7
 
