@@ -68,12 +68,20 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         return 2
+    # rehearsal switch (tests only): ENLSIP_BENCH_DIST_BACKEND=gloo runs the N > 1 control flow with every rank on the
+    # GPUs that exist (local_rank modulo device count) — RCCL refuses two ranks on one device, the one-GPU boxes have one
+    backend = os.environ.get("ENLSIP_BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from enlsip_gn import GNSolver, SQRT_EPS
 
@@ -130,7 +138,7 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

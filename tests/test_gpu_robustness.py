@@ -80,3 +80,22 @@ def test_padded_leading_dimensions_and_strides(B, m, n, t, pj, pa):
     P = pout.cpu().numpy()
     for k in (0, B - 1):
         assert rel(P[k], go.gn_subproblem(*probs[k]).p) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_control_flow_rehearsal():
+    """bench.py's N > 1 path (rendezvous, barriers, MAX over ranks, rank-0 JSON line) with two ranks sharing this box's one GPU:
+    gloo instead of RCCL (which refuses two ranks on one device), everything else as the driver launches it."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ENLSIP_BENCH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "32", "--cpu-budget", "0"]      # (torchrun's own parser trips over --m / --n / --t: default C2 shape)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["results_check"]["finite"]
+    assert rec["value"] > 0 and rec["cpu_baseline"] is None and rec["roofline"]["bound"] == "hbm"
