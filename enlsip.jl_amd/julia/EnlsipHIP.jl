@@ -267,4 +267,36 @@ function jacobian_times_hip(h::Handle, p::Vector{Float64}, m::Integer, t::Intege
     return Jp, Ap
 end
 
+"""    diagR(F::DeviceQR) -> diag(F.R) without moving the triangle (what `pseudo_rank(diag(F.R), ε)` needs, :768, :224)"""
+function diagR(F::DeviceQR)
+    r, c = factor_shape(F)
+    k = min(r, c)
+    dg = zeros(Float64, max(k, 1))
+    GC.@preserve dg check(getfield(F, :h), ccall((:enlsip_gn_get_diagR, LIB), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}),
+                                                 getfield(F, :h).ptr, getfield(F, :which), 0, dg))
+    return dg[1:k]
+end
+
+"""    gn_search_direction_batched_hip(h, Js, rxs, As, cxs, ε_rank) -> (P, infos)
+
+New capability (no reference counterpart): `B` independent subproblems of one shape in one call — `Js` is `m×n×B`, `rxs` `m×B`,
+`As` `t×n×B` (the active constraint Jacobians), `cxs` `t×B`.  Returns the directions as the columns of `P` (`n×B`) and the
+per-problem `Info` records.  Factors stay resident; pass `prob` to the accessors of the C ABI to reach problem `k`.
+"""
+function gn_search_direction_batched_hip(h::Handle, Js::Array{Float64,3}, rxs::Matrix{Float64}, As::Array{Float64,3},
+                                         cxs::Matrix{Float64}, ε_rank::Float64)
+    m, n, B = size(Js)
+    t = size(As, 1)
+    kA = min(n, t)
+    Ats = permutedims(As, (2, 1, 3))                     # n×t×B: every slice is C.A' column-major
+    P = zeros(Float64, n, B); b = zeros(Float64, max(t, 1), B); d = zeros(Float64, m, B)
+    jA = zeros(Int64, max(t, 1), B); jL = zeros(Int64, max(kA, 1), B); jJ = zeros(Int64, n, B)
+    infos = fill(Info(0, 0, 0, 0, 0, 0), B)
+    GC.@preserve Js rxs Ats cxs P b d jA jL jJ infos check(h, ccall((:enlsip_gn_solve_batched, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Int64,
+         Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Info}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+        h.ptr, B, m, n, t, Js, m, m * n, rxs, Ats, max(n, 1), n * t, cxs, ε_rank, P, b, d, infos, jA, jL, jJ))
+    return P, infos
+end
+
 end # module
