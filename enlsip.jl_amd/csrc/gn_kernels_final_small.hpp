@@ -21,7 +21,10 @@ inline size_t final_small_lds_bytes(int kpm, int nv) { return (size_t)(kpm * 65 
 #endif
 
 template <int NR>
-__global__ __launch_bounds__(64) void k_pivot_small(FinalArgs a) {
+#ifndef ENLSIP_PS_OCC
+#define ENLSIP_PS_OCC 0           // measured: 4 waves per SIMD (128 registers, 120 B scratch) more than doubles the kernel's time
+#endif
+__global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : 1) void k_pivot_small(FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int prob = blockIdx.x + a.prob0;
