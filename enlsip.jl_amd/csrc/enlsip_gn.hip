@@ -732,15 +732,21 @@ extern "C" {
 
 int enlsip_gn_version(void) { return 100; }
 
+// why the last enlsip_gn_create of this thread failed (no handle exists to carry the message): enlsip_gn_last_error(NULL)
+static thread_local std::string g_create_err;
+
 int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
     if (!out) return -1;
     *out = nullptr;
+    g_create_err.clear();
     enlsip_gn_context* h = new (std::nothrow) enlsip_gn_context();
-    if (!h) return 998;
+    if (!h) { g_create_err = "out of host memory"; return 998; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev < 1) {
         delete h;
+        g_create_err = std::string("no usable HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                       "): libenlsip_gn has no CPU code path";
         return e != hipSuccess ? (int)e : 100;  // hipErrorNoDevice
     }
     int dev = (opts && opts->device >= 0) ? opts->device : -1;
@@ -749,6 +755,7 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
     }
     if (dev >= ndev) {
         delete h;
+        g_create_err = "opts->device is not a device ordinal of this process";
         return -2;
     }
     h->device = dev;
@@ -819,7 +826,7 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
 }
 
 const char* enlsip_gn_last_error(enlsip_gn_handle h) {
-    if (!h) return "null handle";
+    if (!h) return g_create_err.empty() ? "null handle" : g_create_err.c_str();
     if (h->err.empty() && h->child && !h->child->err.empty()) return h->child->err.c_str();
     return h->err.c_str();
 }

@@ -44,7 +44,8 @@ mutable struct Handle
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         opts = Ref(Opts(Int32(device), Int32(flags), Int32(0), Int32(0), C_NULL))
         rc = ccall((:enlsip_gn_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{Opts}), ref, opts)
-        rc == 0 || error("enlsip_gn_create failed with code $rc")
+        rc == 0 || error("enlsip_gn_create failed with code $rc: " *
+                         unsafe_string(ccall((:enlsip_gn_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
         h = new(ref[])
         finalizer(x -> ccall((:enlsip_gn_destroy, LIB), Cint, (Ptr{Cvoid},), x.ptr), h)
         return h

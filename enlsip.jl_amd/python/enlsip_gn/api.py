@@ -100,7 +100,8 @@ class GNSolver:
                       stream=C.c_void_p(stream) if stream else None)
         rc = self._lib.enlsip_gn_create(C.byref(self._h), C.byref(opts))
         if rc != 0:
-            raise GNError(f"enlsip_gn_create failed with code {rc} (no usable HIP device?)")
+            msg = self._lib.enlsip_gn_last_error(None)
+            raise GNError(f"enlsip_gn_create failed with code {rc}: {msg.decode() if msg else 'no usable HIP device?'}")
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -83,6 +83,7 @@ int enlsip_gn_version(void);
 
 int enlsip_gn_create(enlsip_gn_handle* h, const enlsip_gn_opts* opts);
 int enlsip_gn_destroy(enlsip_gn_handle h);
+/* message of the last failed call on h; h = NULL: why the last enlsip_gn_create of the calling thread failed */
 const char* enlsip_gn_last_error(enlsip_gn_handle h);
 int enlsip_gn_synchronize(enlsip_gn_handle h);
 

@@ -50,3 +50,33 @@ def test_product_does_not_import_oracle():
         assert "oracle" not in txt.replace("CPU oracle under /oracle is test infrastructure only", ""), py
     for src in (ROOT / "enlsip.jl_amd" / "csrc").iterdir():
         assert "oracle/" not in src.read_text().replace("oracle/lapack_semantics.py", ""), src
+
+
+def test_plain_c99_client_compiles_links_and_fails_loudly_without_gpu(lib, tmp_path):
+    """tests/c_abi_client.c: a C99 translation unit (gcc -std=c99 -pedantic, no C++ / HIP headers) that includes the header,
+    links the library and solves a small problem.  Here (no GPU) it must get a refusal WITH a message from enlsip_gn_create;
+    on a GPU box the same binary is the `-m gpu` test below."""
+    import subprocess, torch
+    exe = tmp_path / "c_abi_client"
+    libdir = ROOT / "enlsip.jl_amd" / "lib"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}",
+                    str(ROOT / "tests" / "c_abi_client.c"), "-o", str(exe), f"-L{libdir}", "-lenlsip_gn", "-lm",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert out.returncode == 0, out.stdout
+    else:
+        assert out.returncode == 3 and "no usable HIP device" in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c99_client_solves_on_gpu(lib, tmp_path):
+    import subprocess
+    exe = tmp_path / "c_abi_client"
+    libdir = ROOT / "enlsip.jl_amd" / "lib"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}",
+                    str(ROOT / "tests" / "c_abi_client.c"), "-o", str(exe), f"-L{libdir}", "-lenlsip_gn", "-lm",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "worst optimality residual" in out.stdout
