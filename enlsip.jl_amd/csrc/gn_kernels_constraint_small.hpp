@@ -20,7 +20,10 @@ template <int NR>
 #ifndef ENLSIP_CS_OCC
 #define ENLSIP_CS_OCC 3           // NR = 32: 168 registers without spills, 3 waves per SIMD instead of 2 (C5 constraint stage 0.117 -> 0.098 ms)
 #endif
-__global__ __launch_bounds__(64, (NR == 32 && ENLSIP_CS_OCC) ? ENLSIP_CS_OCC : 1) void k_constraint_small(ConstraintArgs a) {
+#ifndef ENLSIP_CS64_OCC
+#define ENLSIP_CS64_OCC 0         // measured: 2 waves per SIMD = 420 spilled registers, C3 constraint stage 0.07 -> 0.13 ms
+#endif
+__global__ __launch_bounds__(64, (NR == 32 && ENLSIP_CS_OCC) ? ENLSIP_CS_OCC : ((NR == 64 && ENLSIP_CS64_OCC) ? ENLSIP_CS64_OCC : 1)) void k_constraint_small(ConstraintArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n = a.n, t = a.t, kA = a.kA;
     const int kd = kA > 0 ? kA : 1;

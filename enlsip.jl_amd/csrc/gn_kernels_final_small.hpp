@@ -24,7 +24,10 @@ template <int NR>
 #ifndef ENLSIP_PS_OCC
 #define ENLSIP_PS_OCC 0           // measured: 4 waves per SIMD (128 registers, 120 B scratch) more than doubles the kernel's time
 #endif
-__global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : 1) void k_pivot_small(FinalArgs a) {
+#ifndef ENLSIP_PS64_OCC
+#define ENLSIP_PS64_OCC 0         // measured: 2 waves per SIMD = 152 spilled registers, C3 pivot stage 0.19 -> 0.36 ms
+#endif
+__global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : ((NR == 64 && ENLSIP_PS64_OCC) ? ENLSIP_PS64_OCC : 1)) void k_pivot_small(FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int prob = blockIdx.x + a.prob0;

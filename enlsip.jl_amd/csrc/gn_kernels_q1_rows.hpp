@@ -15,7 +15,10 @@ template <int NMAX>
 #ifndef ENLSIP_JR_OCC
 #define ENLSIP_JR_OCC 0           // measured: no gain at 4 waves per SIMD, 5x slower at 5 (380 B scratch)
 #endif
-__global__ __launch_bounds__(256, (NMAX == 32 && ENLSIP_JR_OCC) ? ENLSIP_JR_OCC : 1) void k_jq1_rows(JQ1Args a) {
+#ifndef ENLSIP_JR64_OCC
+#define ENLSIP_JR64_OCC 0         // measured: 2 waves per SIMD = 88 spilled registers, C3 J*Q1 stage 0.19 -> 0.29 ms
+#endif
+__global__ __launch_bounds__(256, (NMAX == 32 && ENLSIP_JR_OCC) ? ENLSIP_JR_OCC : ((NMAX == 64 && ENLSIP_JR64_OCC) ? ENLSIP_JR64_OCC : 1)) void k_jq1_rows(JQ1Args a) {
     __shared__ __attribute__((aligned(16))) double Vs[Q1R_MAXK * NMAX];   // Vs[k][c] = v_k[c] (unit diagonal, zeros above)
     __shared__ double taus[Q1R_MAXK];
     __shared__ double p1s[NMAX];
