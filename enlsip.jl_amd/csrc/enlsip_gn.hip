@@ -231,7 +231,9 @@ static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
     // one-tile problems of at most 256 rows: 4 waves x 8 columns issue ~20 % fewer instructions per step than 8 x 4
     // (measured on C5: panel stage 0.63 -> 0.57 ms); everywhere else the 8-wave form wins
     const bool four = (h->factor_waves != 8) || (h->plan.m <= 256 && !getenv("ENLSIP_GN_FACTOR_WAVES"));
-    if (!four) {
+    if (h->factor_waves == 16 && h->plan.RPL == 8) {
+        hipLaunchKernelGGL((k_caqr_factor<8, 16>), grid, dim3(1024), 0, h->stream, a);
+    } else if (!four) {
         if (h->plan.RPL == 8) hipLaunchKernelGGL((k_caqr_factor<8, 8>), grid, dim3(512), 0, h->stream, a);
         else hipLaunchKernelGGL((k_caqr_factor<4, 8>), grid, dim3(512), 0, h->stream, a);
     } else {
@@ -773,6 +775,7 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (qm && qm[0] == 's') h->qrcp_mode = 1;            // step: one launch per pivot step
         const char* fw = getenv("ENLSIP_GN_FACTOR_WAVES");   // 4 or 8 waves per panel-factor workgroup (A/B switch)
         if (fw && fw[0] == '4') h->factor_waves = 4;
+        if (fw && fw[0] == '1' && fw[1] == '6') h->factor_waves = 16;
         h->trace = getenv("ENLSIP_GN_TRACE") != nullptr;
         const char* pl = getenv("ENLSIP_GN_PIPELINE");       // 0: never split a batch over two streams
         if (pl && pl[0] == '0') h->pipeline = false;

@@ -90,7 +90,7 @@ struct enlsip_gn_context {
     long long split = 0;                // problems [split, batch) of the last solve live on `child` (0: not split)
     hipEvent_t ev_fork = nullptr;
     long long tsqr_n2 = -1;             // n2 of the last tsqr_local on this handle
-    int factor_waves = 8;   // waves per workgroup of k_caqr_factor (ENLSIP_GN_FACTOR_WAVES=4 selects the 4-wave form)
+    int factor_waves = 8;   // waves per workgroup of k_caqr_factor (ENLSIP_GN_FACTOR_WAVES=4 / 16 select the 4- / 16-wave forms; measured slower)
     int qrcp_mode = 2;   // 0 persistent (co-resident workgroups), 1 one launch per pivot step, 2 blocked with verified pivots
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
     gn::ProbState* state = nullptr;

@@ -134,6 +134,21 @@ __device__ __forceinline__ void wave_allsum4(const double (&d)[4], double (&out)
     for (int c = 0; c < 4; ++c) out[c] = readlane_f64(k1, 4 * (c >> 1) + 2 * (c & 1));
 }
 __device__ __forceinline__ void wave_allsumN(const double (&d)[8], double (&out)[8]) { wave_allsum8(d, out); }
+// two columns: lane bit 1 decides which column a lane keeps after the first level
+__device__ __forceinline__ void wave_allsumN(const double (&d)[2], double (&out)[2]) {
+    const int ln = threadIdx.x & 63;
+    const bool b1 = (ln & 2) != 0;
+    const double mine = b1 ? d[1] : d[0];
+    const double give = b1 ? d[0] : d[1];
+    double k1 = mine + dpp_f64<0x1B>(give);    // quad_perm [3,2,1,0]: partner has the other bit 1
+    k1 += dpp_f64<0xB1>(k1);                   // quad_perm [1,0,3,2]
+    k1 += dpp_f64<0x124>(k1);                  // row_ror:4  (partners share bit 1)
+    k1 += dpp_f64<0x128>(k1);                  // row_ror:8
+    k1 = xor16_sum(k1);
+    k1 = xor32_sum(k1);
+    out[0] = readlane_f64(k1, 0);
+    out[1] = readlane_f64(k1, 2);
+}
 __device__ __forceinline__ void wave_allsumN(const double (&d)[4], double (&out)[4]) { wave_allsum4(d, out); }
 
 template <int CTRL>

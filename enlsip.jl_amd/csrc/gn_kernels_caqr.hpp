@@ -57,7 +57,10 @@ template <int RPL, int NW>
 #ifndef ENLSIP_FACTOR_OCC4
 #define ENLSIP_FACTOR_OCC4 4      // one-tile problems of <= 256 rows (RPL 4, 4 waves): 128 registers, 4 workgroups per CU: C5 +4 % (2: 150 registers)
 #endif
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ENLSIP_FACTOR_OCC8 : (RPL == 4 ? ENLSIP_FACTOR_OCC4 : 2)) void k_caqr_factor(CaqrArgs a) {   // 2nd bound = waves per SIMD
+#ifndef ENLSIP_FACTOR_OCC16
+#define ENLSIP_FACTOR_OCC16 8
+#endif
+__global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 ? ENLSIP_FACTOR_OCC8 : (RPL == 4 ? ENLSIP_FACTOR_OCC4 : 2))) void k_caqr_factor(CaqrArgs a) {   // 2nd bound = waves per SIMD
     constexpr int NC = PB / NW;
     constexpr int NT = 64 * NW;
     __shared__ double vsh[2][64 * RPL];
