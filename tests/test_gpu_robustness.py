@@ -99,3 +99,50 @@ def test_bench_two_rank_control_flow_rehearsal():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["results_check"]["finite"]
     assert rec["value"] > 0 and rec["cpu_baseline"] is None and rec["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+def test_raw_abi_rejects_bad_arguments_without_touching_the_device():
+    """LAPACK-style argument checks of the C ABI (include/enlsip_gn.h: < 0 = bad argument): null pointers, short leading
+    dimensions, dimensions outside this build's limits, accessors before any solve and out-of-range problem indices must all
+    come back as error codes with a message — never as a launch with those values."""
+    import ctypes as C
+    from enlsip_gn import GNSolver, SQRT_EPS
+    import enlsip_gn._lib as L
+    s = GNSolver(device=0)
+    lib, h = s._lib, s._h
+    fp = lambda a: a.ctypes.data_as(C.c_void_p)
+    m, n, t = 40, 6, 2
+    J, rx, A, cx = synth.make_problem(5, m, n, t)
+    Jf = np.asfortranarray(J); At = np.asfortranarray(A.T)
+    p, b, d = np.zeros(n), np.zeros(t), np.zeros(m)
+    info = L.Info()
+    jA, jL, jJ = np.zeros(t, np.int64), np.zeros(t, np.int64), np.zeros(n, np.int64)
+
+    def solve(mm=m, nn=n, tt=t, Jp=fp(Jf), ldj=m, rxp=fp(rx), Atp=fp(At), ldat=n, cxp=fp(cx)):
+        return lib.enlsip_gn_solve(h, mm, nn, tt, Jp, ldj, rxp, Atp, ldat, cxp, SQRT_EPS, -1, -1, fp(p), fp(b), fp(d),
+                                   C.byref(info), fp(jA), fp(jL), fp(jJ))
+
+    # accessors before any solve
+    r, c = C.c_int64(0), C.c_int64(0)
+    assert lib.enlsip_gn_factor_shape(h, 0, 0, C.byref(r), C.byref(c)) != 0
+    assert lib.enlsip_gn_get_R(h, 2, 0, fp(np.zeros(36)), 6) != 0
+    assert lib.enlsip_gn_resolve(h, 0, 1, 1, -1, fp(p), fp(b), fp(d)) != 0
+    for bad in (dict(mm=0), dict(mm=-3), dict(nn=0), dict(nn=1025), dict(tt=-1), dict(tt=1025), dict(Jp=None), dict(ldj=m - 1),
+                dict(rxp=None), dict(Atp=None), dict(cxp=None), dict(ldat=n - 1)):
+        rc = solve(**bad)
+        assert rc < 0, (bad, rc)
+        assert lib.enlsip_gn_last_error(h)                      # a message, not an empty string
+    assert solve() == 0                                         # and the handle still works
+    ref = go.gn_subproblem(J, rx, A, cx)
+    assert np.linalg.norm(p - ref.p) <= 1e-11 * np.linalg.norm(ref.p)
+    # out-of-range problem index / factor id / dimensions on the resident factors
+    assert lib.enlsip_gn_factor_shape(h, 0, 1, C.byref(r), C.byref(c)) != 0
+    assert lib.enlsip_gn_factor_shape(h, 7, 0, C.byref(r), C.byref(c)) != 0
+    assert lib.enlsip_gn_get_R(h, 2, 0, fp(np.zeros(36)), 1) != 0          # ldr < rows
+    assert lib.enlsip_gn_get_R(h, 2, 0, None, 6) != 0
+    assert lib.enlsip_gn_resolve(h, 0, t + 1, n - t, -1, fp(p), fp(b), fp(d)) != 0
+    assert lib.enlsip_gn_resolve(h, 0, t, n - t + 1, -1, fp(p), fp(b), fp(d)) != 0
+    assert lib.enlsip_gn_apply_qt(h, 2, 0, None) != 0
+    assert solve() == 0
+    s.close()
