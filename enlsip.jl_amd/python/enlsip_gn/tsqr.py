@@ -90,9 +90,18 @@ def tsqr_solve(solver: Optional[GNSolver], J_loc, rx_loc, At, cx, eps_rank: floa
     zstack = torch.empty((G * n2,), dtype=torch.float64, device=dev)
     tails = torch.tensor([tail], dtype=torch.float64, device=dev)
     if G > 1:
-        dist.all_gather_into_tensor(Rstack, R[: n2 * n2].contiguous(), group=group)
-        dist.all_gather_into_tensor(zstack, z[:n2].contiguous(), group=group)
-        dist.all_reduce(tails, op=dist.ReduceOp.SUM, group=group)
+        if dev.type == "cuda" and dist.get_backend(group) != "nccl":
+            # rehearsal only (several ranks on one GPU under gloo, tests/tsqr_rank_worker.py): RCCL refuses two ranks on one
+            # device, gloo moves host tensors
+            Rc, zc, tc = torch.empty(Rstack.shape, dtype=torch.float64), torch.empty(zstack.shape, dtype=torch.float64), tails.cpu()
+            dist.all_gather_into_tensor(Rc, R[: n2 * n2].cpu().contiguous(), group=group)
+            dist.all_gather_into_tensor(zc, z[:n2].cpu().contiguous(), group=group)
+            dist.all_reduce(tc, op=dist.ReduceOp.SUM, group=group)
+            Rstack.copy_(Rc); zstack.copy_(zc); tails.copy_(tc)
+        else:
+            dist.all_gather_into_tensor(Rstack, R[: n2 * n2].contiguous(), group=group)
+            dist.all_gather_into_tensor(zstack, z[:n2].contiguous(), group=group)
+            dist.all_reduce(tails, op=dist.ReduceOp.SUM, group=group)
     else:
         Rstack.copy_(R[: n2 * n2])
         zstack.copy_(z[:n2])

@@ -146,3 +146,17 @@ def test_raw_abi_rejects_bad_arguments_without_touching_the_device():
     assert lib.enlsip_gn_apply_qt(h, 2, 0, None) != 0
     assert solve() == 0
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_tsqr_driver_with_real_ranks_on_the_device(world):
+    """enlsip_gn.tsqr.tsqr_solve as a real collective: `world` processes, each with its own handle and row block on the GPU
+    (tests/tsqr_rank_worker.py), gloo between them on this one-GPU box; every rank must reproduce the oracle's single solve."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29540 + world), os.path.join(root, "tests", "tsqr_rank_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.stdout.count(" ok") == 3 * world and "FAIL" not in out.stdout
