@@ -189,13 +189,18 @@ def main() -> int:
             # HBM bytes per launch from the committed PMC passes of this same command and workload
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/): PMC counters
             # cannot be collected from inside the run, so the figure is carried only for a matching config.
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1e_update_traffic_pmc.json")
-            if os.path.exists(pmc):
+            # (two separate --pmc passes post-processed by tests/pmc_update_traffic.py)
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            for name in ("r1h_update_traffic_pmc.json", "r1e_update_traffic_pmc.json"):      # newest first
+                pmc = os.path.join(pdir, name)
+                if not os.path.exists(pmc):
+                    continue
                 with open(pmc) as fh:
                     rec = json.load(fh)
                 if rec.get("config") == {"m": m, "n": n, "t": t, "batch": B}:
                     roofline["traffic"] = rec["hbm_bytes_per_launch_avg"]
-                    roofline["traffic_source"] = "profiles/r1e_update_traffic_pmc.json"
+                    roofline["traffic_source"] = "profiles/" + name
+                    break
 
     # whole-solve figures from SURVEY section 8(d)'s per-solve formulas (full rank, n2 = n - t): every operand crosses HBM
     # once per direction; flops of the LAPACK sequence the path replaces

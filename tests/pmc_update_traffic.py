@@ -1,0 +1,56 @@
+"""HBM traffic of the level-0 trailing update from two rocprofv3 PMC passes (diagnostic / evidence tooling, not a test).
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out_f -- python3 bench.py --steps 1 --warmup 1 --cpu-budget 0 --no-roofline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out_w -- python3 bench.py --steps 1 --warmup 1 --cpu-budget 0 --no-roofline
+    python3 tests/pmc_update_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json] [batch=384]
+
+Counters are collected in separate passes (one counter per run) and corrected as MI355X_MICROARCH.md's HBM / rocprofv3 section
+prescribes for gfx950: FETCH_SIZE (KB) tallies 128-byte read requests at 64 bytes -> doubled; WRITE_SIZE (KB) as reported.
+The timed step runs as two pipelined halves, so the launches of the LAST 2 x 14 level-0 updates are taken and normalised to the
+14 whole-batch launches that bench.py's roofline leg times: bytes per launch = sum over the 28 half launches / 14."""
+import csv, json, sys
+
+KERNEL = "k_caqr_update_v4<8, false>"
+
+
+def last_launches(path, counter, count):
+    vals = []
+    for r in csv.DictReader(open(path)):
+        # the single-problem launches of bench.py's latency leg come last and are skipped by their grid (< 10^5 threads)
+        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) > 100000:
+            vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    vals.sort()
+    return [v for _, v in vals[-count:]]
+
+
+def main():
+    fpath, wpath = sys.argv[1], sys.argv[2]
+    out = sys.argv[3] if len(sys.argv) > 3 else None
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 384
+    m, n, t, PB = 4096, 512, 64, 32
+    npan = (n - t + PB - 1) // PB
+    nl = 2 * (npan)                       # two halves x panels with a trailing update (the last panel carries only d)
+    fetch = last_launches(fpath, "FETCH_SIZE", nl)
+    write = last_launches(wpath, "WRITE_SIZE", nl)
+    assert len(fetch) == nl and len(write) == nl, (len(fetch), len(write), nl)
+    hbm = (2.0 * sum(fetch) + sum(write)) * 1024.0 / npan
+    alg = 0.0
+    for k in range(npan):
+        mk = m - k * PB
+        ntrail = (n - t) - (k + 1) * PB + 1          # remaining columns of J2 plus the carried right-hand side
+        if ntrail > 0:
+            alg += batch * 8.0 * (2.0 * mk * ntrail + mk * PB + PB * PB)
+    alg /= npan
+    rec = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --steps 1 --warmup 1 --cpu-budget 0 --no-roofline",
+           "kernel": KERNEL, "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
+           "correction": "gfx950: FETCH_SIZE doubled (128-B requests tallied at 64 B), WRITE_SIZE as reported",
+           "hbm_bytes_per_launch_avg": hbm, "algorithmic_bytes_per_launch_avg": alg, "ratio": hbm / alg,
+           "config": {"m": m, "n": n, "t": t, "batch": batch}}
+    print(json.dumps({k: rec[k] for k in ("hbm_bytes_per_launch_avg", "algorithmic_bytes_per_launch_avg", "ratio")}))
+    if out:
+        json.dump(rec, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
