@@ -779,6 +779,7 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         h->trace = getenv("ENLSIP_GN_TRACE") != nullptr;
         const char* pl = getenv("ENLSIP_GN_PIPELINE");       // 0: never split a batch over two streams
         if (pl && pl[0] == '0') h->pipeline = false;
+        if (pl && pl[0] == '1') h->pipeline_forced = true;    // 1: split even the small uniform shapes (A/B)
     }
     if (opts && opts->panel_width != 0 && opts->panel_width != PB) {
         delete h;
@@ -872,7 +873,10 @@ int enlsip_gn_solve_batched_dev(enlsip_gn_handle h, int64_t batch, int64_t m, in
     if (!drx) return -9;
     if (t > 0 && (!dAt || !dcx)) return -10;
     h->split = 0;
-    if (h->pipeline && !h->profiling && batch >= h->pipeline_min) {
+    // one-tile problems of the wave-per-problem pipeline (n <= 64, m <= 512: C3, C5) are a handful of short, uniform launches with
+    // nothing latency-bound to hide behind them: the split costs C3 4 % (1.276 -> 1.325 M solves/s without it), C5 nothing
+    const bool small_uniform = (n <= 64 && m <= 512) && !h->pipeline_forced;
+    if (h->pipeline && !h->profiling && batch >= h->pipeline_min && !small_uniform) {
         // two halves on two streams (see gn_context.hpp); the child's stream is ordered after everything the caller
         // has enqueued on this handle's stream, and both halves are complete when this call returns
         GN_HIP(hipSetDevice(h->device));

@@ -86,6 +86,7 @@ struct enlsip_gn_context {
     // overlap the bandwidth-bound kernels of the other.  Accessors route a problem index to the half that owns it.
     enlsip_gn_context* child = nullptr;
     bool pipeline = true;               // ENLSIP_GN_PIPELINE=0 disables
+    bool pipeline_forced = false;   // ENLSIP_GN_PIPELINE=1
     long long pipeline_min = 128;       // smallest batch that is split
     long long split = 0;                // problems [split, batch) of the last solve live on `child` (0: not split)
     hipEvent_t ev_fork = nullptr;

@@ -7,6 +7,8 @@ import numpy as np, torch
 from oracle import gn_oracle as go, synth
 from enlsip_gn import GNSolver, SQRT_EPS
 dev = torch.device("cuda", 0)
+import os
+os.environ.setdefault("ENLSIP_GN_PIPELINE", "1")     # split the small shapes too
 s = GNSolver(device=0)
 bad = 0
 for (B, m, n, t) in [(256, 300, 40, 6), (192, 700, 200, 30), (160, 600, 300, 80), (256, 256, 32, 4)]:

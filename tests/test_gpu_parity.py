@@ -4,6 +4,8 @@ through size-independent properties.  Tolerances are the ones SURVEY.md §8(c) s
 well-conditioned: ||p - p_oracle|| / ||p_oracle|| <= 1e-11, ranks equal, |diag R| rel 1e-12-ish,
 jpvt equal on tie-free inputs; ill-conditioned (cond up to 1e8): forward error <= 1e-13 * cond.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -190,12 +192,16 @@ def test_batched_matches_single(batch, m, n, t, solver):
             assert np.array_equal(jJ[k][:n - ref.rankA], ref.jpvtJ2)
 
 
-def test_pipelined_device_batch_matches_oracle(solver):
+@pytest.mark.parametrize("shape", [(131, 96, 12, 2), (130, 700, 70, 5)])
+def test_pipelined_device_batch_matches_oracle(shape, monkeypatch):
     """A device-pointer batch >= 128 is split over two streams inside the library (second half on a child
-    handle): every problem must still match the oracle, and accessors must reach both halves."""
+    handle): every problem must still match the oracle, and accessors must reach both halves.  The first shape belongs to
+    the small uniform ones that are not split by default (ENLSIP_GN_PIPELINE=1 forces it), the second one is split by default."""
     import torch
-    from enlsip_gn import FACTOR_J2
-    batch, m, n, t = 131, 96, 12, 2
+    from enlsip_gn import FACTOR_J2, GNSolver
+    batch, m, n, t = shape
+    monkeypatch.setenv("ENLSIP_GN_PIPELINE", "1")
+    solver = GNSolver(device=0)
     dev = torch.device("cuda", 0)
     Js, rxs, Ats, cxs, refs = [], [], [], [], []
     for k in range(batch):
@@ -216,10 +222,11 @@ def test_pipelined_device_batch_matches_oracle(solver):
     for k, ref in enumerate(refs):
         assert rel(p[k], ref.p) <= TOL_P, k
         assert np.array_equal(jJ[k][:n - ref.rankA], ref.jpvtJ2), k
-    for k in (0, 65, 66, 130):          # both sides of the split at (131 + 1) // 2 = 66
+    for k in (0, 64, 65, 66, batch - 1):          # both sides of the split at (batch + 1) // 2
         F = solver.factor(FACTOR_J2, prob=k)
         assert np.array_equal(F.p, refs[k].jpvtJ2)
         assert np.allclose(np.abs(F.diagR()), np.abs(np.diag(refs[k].F_J2.R)[: len(F.diagR())]), rtol=1e-9, atol=1e-12)
+    solver.close()
 
 
 @pytest.mark.parametrize("kind,m,n,t", [
@@ -301,7 +308,11 @@ def test_pipelined_batch_on_caller_stream():
     hrx = torch.from_numpy(np.stack(rxs)).pin_memory()
     hAt = torch.from_numpy(np.stack(Ats)).pin_memory()
     hcx = torch.from_numpy(np.stack(cxs)).pin_memory()
-    s = GNSolver(device=0, stream=st.cuda_stream)
+    os.environ["ENLSIP_GN_PIPELINE"] = "1"                          # this small shape is not split by default
+    try:
+        s = GNSolver(device=0, stream=st.cuda_stream)
+    finally:
+        del os.environ["ENLSIP_GN_PIPELINE"]
     try:
         with torch.cuda.stream(st):
             big = torch.randn(64, 1024, 1024, device=dev)          # keeps the stream busy for a while
