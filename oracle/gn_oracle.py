@@ -40,6 +40,10 @@ sqrt(eps), docs/src/tutorial.md:201-211).  Status:
     pinned end to end on the reference's HS65 known answer;
     no reference vectors exist at the subproblem boundary itself (unpinned there).
 
+Independent of the reference: the same outer loop reaches the published solutions of nineteen further least-squares problems
+of the Hock-Schittkowski collection (tests/hs_problems.py, tests/test_hs_set.py) — a check of the restatement against the
+literature, not a reference vector.
+
 Conventions: column-major semantics are irrelevant in NumPy, but every permutation
 returned is the **1-based LAPACK jpvt** exactly as Julia's ``F.p``.
 """
