@@ -43,6 +43,23 @@ using namespace gn;
         }                                                                              \
     } while (0)
 
+// No exception crosses the ABI: entry points that allocate on the host (std::vector, std::string, std::thread) run inside
+// GN_TRY ... GN_CATCH(h), which turns an exception into an error code and a message.
+#define GN_TRY try {
+#define GN_CATCH(h)                                                                    \
+    }                                                                                  \
+    catch (const std::bad_alloc&) {                                                    \
+        try { (h)->err = "out of host memory"; } catch (...) {}                        \
+        return 998;                                                                    \
+    }                                                                                  \
+    catch (const std::exception& e__) {                                                \
+        try { (h)->err = std::string("host exception: ") + e__.what(); } catch (...) {}\
+        return 997;                                                                    \
+    }                                                                                  \
+    catch (...) {                                                                      \
+        return 997;                                                                    \
+    }
+
 static inline long long rup(long long x, long long a) { return (x + a - 1) / a * a; }
 
 #define GN_TRACE(h, ...)                                              \
@@ -172,8 +189,13 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     return 0;
 }
 
+// Problems per launch: the batch index is a grid y / z dimension (limit 65535).  Larger batches are cut into
+// consecutive chunks by solve_chunked; the limit is kept a power of two so that C5's 65536 problems are two even chunks.
+constexpr long long GN_MAX_LAUNCH_BATCH = 32768;
+
 static int check_limits(enlsip_gn_handle h, long long batch, long long m, long long n, long long t) {
     if (batch < 1) { h->err = "batch must be >= 1"; return -2; }
+    if (batch > (1LL << 31) - 1) { h->err = "batch must be < 2^31"; return -2; }
     if (m < 1 || m > (1LL << 27)) { h->err = "m out of range (1 .. 2^27: 32-bit lane offsets in the update kernel)"; return -3; }
     if (n < 1 || n > 1024) { h->err = "n must be in 1..1024 in this build"; return -4; }
     if (t < 0 || t > 1024) { h->err = "t must be in 0..1024 in this build"; return -5; }
@@ -578,8 +600,9 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
                      const double* dAt, long long ldat, long long strideAt, const double* dcx,
                      double eps_rank, long long dimA_ov, long long dimJ2_ov,
                      double* dp, double* db, double* dd, enlsip_gn_info* dinfo,
-                     long long* djA, long long* djL, long long* djJ) {
+                     long long* djA, long long* djL, long long* djJ, enlsip_gn_info* hinfo = nullptr) {
     h->split = 0;   // routing of accessors to the pipeline child is (re)established by the batched entry point
+    h->chunk0 = 0;  // ... and to the resident chunk by solve_chunked
     const bool reuse = h->reuse_once;
     h->reuse_once = false;
     int rc = check_limits(h, batch, m, n, t);
@@ -693,6 +716,11 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         if (n2max <= n2_launch) break;
         n2_launch = n2max;  // some A was rank deficient: J2 is wider than speculated, redo from J*Q1
     }
+    if (hinfo)
+        for (long long k = 0; k < batch; ++k) {
+            const ProbState& st = h->h_state[k];
+            hinfo[k] = {st.rankA, st.rankJ2, st.code, st.dimA, st.dimJ2, st.status};
+        }
     if (dinfo) {
         // info records are produced on the host from the state mirror and copied to the device buffer
         std::vector<enlsip_gn_info> tmp((size_t)batch);
@@ -730,9 +758,11 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+static void tsqr_drop_comm(enlsip_gn_handle h);      // gn_tsqr.inc
+
 extern "C" {
 
-int enlsip_gn_version(void) { return 100; }
+int enlsip_gn_version(void) { return 200; }
 
 // why the last enlsip_gn_create of this thread failed (no handle exists to carry the message): enlsip_gn_last_error(NULL)
 static thread_local std::string g_create_err;
@@ -816,6 +846,8 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->lag.p) (void)hipFree(h->lag.p);
     if (h->cws.p) (void)hipFree(h->cws.p);
     if (h->scratch.p) (void)hipFree(h->scratch.p);
+    if (h->xbuf.p) (void)hipFree(h->xbuf.p);
+    tsqr_drop_comm(h);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_sbinfo) (void)hipHostFree(h->h_sbinfo);
     if (h->ev_ready)
@@ -863,20 +895,18 @@ int enlsip_gn_get_update_stats(enlsip_gn_handle h, float* avg_ms, int64_t* launc
     return 0;
 }
 
-int enlsip_gn_solve_batched_dev(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t,
-                                const double* dJ, int64_t ldj, int64_t strideJ, const double* drx,
-                                const double* dAt, int64_t ldat, int64_t strideAt, const double* dcx,
-                                double eps_rank, double* dp, double* db, double* dd, enlsip_gn_info* dinfo,
-                                int64_t* djpvtA, int64_t* djpvtL, int64_t* djpvtJ2) {
-    if (!h) return -1;
-    if (!dJ) return -6;
-    if (!drx) return -9;
-    if (t > 0 && (!dAt || !dcx)) return -10;
+// One launch set over at most GN_MAX_LAUNCH_BATCH problems: either two pipelined halves on two streams or one solve_dev.
+static int solve_launchable(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t,
+                            const double* dJ, int64_t ldj, int64_t strideJ, const double* drx,
+                            const double* dAt, int64_t ldat, int64_t strideAt, const double* dcx,
+                            double eps_rank, int64_t dimA_ov, int64_t dimJ2_ov, double* dp, double* db, double* dd,
+                            enlsip_gn_info* dinfo, long long* djA, long long* djL, long long* djJ, enlsip_gn_info* hinfo) {
     h->split = 0;
     // one-tile problems of the wave-per-problem pipeline (n <= 64, m <= 512: C3, C5) are a handful of short, uniform launches with
     // nothing latency-bound to hide behind them: the split costs C3 4 % (1.276 -> 1.325 M solves/s without it), C5 nothing
     const bool small_uniform = (n <= 64 && m <= 512) && !h->pipeline_forced;
-    if (h->pipeline && !h->profiling && batch >= h->pipeline_min && !small_uniform) {
+    const bool plain = (dimA_ov < 0 && dimJ2_ov < 0 && !h->reuse_once);
+    if (plain && h->pipeline && !h->profiling && batch >= h->pipeline_min && !small_uniform) {
         // two halves on two streams (see gn_context.hpp); the child's stream is ordered after everything the caller
         // has enqueued on this handle's stream, and both halves are complete when this call returns
         GN_HIP(hipSetDevice(h->device));
@@ -898,22 +928,75 @@ int enlsip_gn_solve_batched_dev(enlsip_gn_handle h, int64_t batch, int64_t m, in
         int rc1 = 0;
         std::thread worker([&] {
             (void)hipSetDevice(c->device);
-            rc1 = solve_dev(c, b1, m, n, t, dJ + b0 * strideJ, ldj, strideJ, drx + b0 * m, dAt ? dAt + b0 * strideAt : nullptr,
-                            ldat, strideAt, dcx ? dcx + b0 * t : nullptr, eps_rank, -1, -1, dp ? dp + b0 * n : nullptr,
-                            db ? db + b0 * t : nullptr, dd ? dd + b0 * m : nullptr, dinfo ? dinfo + b0 : nullptr,
-                            djpvtA ? (long long*)djpvtA + b0 * t : nullptr, djpvtL ? (long long*)djpvtL + b0 * kA : nullptr,
-                            djpvtJ2 ? (long long*)djpvtJ2 + b0 * n : nullptr);
+            try {
+                rc1 = solve_dev(c, b1, m, n, t, dJ + b0 * strideJ, ldj, strideJ, drx + b0 * m, dAt ? dAt + b0 * strideAt : nullptr,
+                                ldat, strideAt, dcx ? dcx + b0 * t : nullptr, eps_rank, -1, -1, dp ? dp + b0 * n : nullptr,
+                                db ? db + b0 * t : nullptr, dd ? dd + b0 * m : nullptr, dinfo ? dinfo + b0 : nullptr,
+                                djA ? djA + b0 * t : nullptr, djL ? djL + b0 * kA : nullptr, djJ ? djJ + b0 * n : nullptr,
+                                hinfo ? hinfo + b0 : nullptr);
+            } catch (...) {
+                c->err = "exception in the second pipeline half (out of host memory?)";
+                rc1 = 997;
+            }
         });
-        const int rc0 = solve_dev(h, b0, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, -1, -1, dp, db,
-                                  dd, dinfo, (long long*)djpvtA, (long long*)djpvtL, (long long*)djpvtJ2);
+        int rc0;
+        try {
+            rc0 = solve_dev(h, b0, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, -1, -1, dp, db,
+                            dd, dinfo, djA, djL, djJ, hinfo);
+        } catch (...) {
+            worker.join();
+            throw;
+        }
         worker.join();
         if (rc0) return rc0;
         if (rc1) { h->err = c->err; return rc1; }
         h->split = b0;
         return 0;
     }
-    return solve_dev(h, batch, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, -1, -1, dp, db,
-                     dd, dinfo, (long long*)djpvtA, (long long*)djpvtL, (long long*)djpvtJ2);
+    return solve_dev(h, batch, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, dimA_ov, dimJ2_ov, dp, db,
+                     dd, dinfo, djA, djL, djJ, hinfo);
+}
+
+// Any batch: consecutive chunks of at most GN_MAX_LAUNCH_BATCH problems (the problem index is a grid y / z dimension).  The
+// factors that stay resident are those of the LAST chunk; accessors address problems by their index in the whole batch and
+// report an error for the earlier chunks (gn_accessors.inc: need_factors).
+static int solve_chunked(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t,
+                         const double* dJ, int64_t ldj, int64_t strideJ, const double* drx,
+                         const double* dAt, int64_t ldat, int64_t strideAt, const double* dcx,
+                         double eps_rank, int64_t dimA_ov, int64_t dimJ2_ov, double* dp, double* db, double* dd,
+                         enlsip_gn_info* dinfo, long long* djA, long long* djL, long long* djJ, enlsip_gn_info* hinfo) {
+    h->chunk0 = 0;
+    const int64_t kA = std::min(n, t);
+    const int64_t nchunks = (batch + GN_MAX_LAUNCH_BATCH - 1) / GN_MAX_LAUNCH_BATCH;
+    const int64_t per = (batch + nchunks - 1) / nchunks;
+    for (int64_t c0 = 0; c0 < batch; c0 += per) {
+        const int64_t nb = std::min(per, batch - c0);
+        int rc = solve_launchable(h, nb, m, n, t, dJ + c0 * strideJ, ldj, strideJ, drx + c0 * m,
+                                  dAt ? dAt + c0 * strideAt : nullptr, ldat, strideAt, dcx ? dcx + c0 * t : nullptr, eps_rank,
+                                  dimA_ov, dimJ2_ov, dp ? dp + c0 * n : nullptr, db ? db + c0 * t : nullptr,
+                                  dd ? dd + c0 * m : nullptr, dinfo ? dinfo + c0 : nullptr, djA ? djA + c0 * t : nullptr,
+                                  djL ? djL + c0 * kA : nullptr, djJ ? djJ + c0 * n : nullptr, hinfo ? hinfo + c0 : nullptr);
+        if (rc) return rc;
+        h->chunk0 = c0;
+    }
+    return 0;
+}
+
+int enlsip_gn_solve_batched_dev(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t,
+                                const double* dJ, int64_t ldj, int64_t strideJ, const double* drx,
+                                const double* dAt, int64_t ldat, int64_t strideAt, const double* dcx,
+                                double eps_rank, double* dp, double* db, double* dd, enlsip_gn_info* dinfo,
+                                int64_t* djpvtA, int64_t* djpvtL, int64_t* djpvtJ2) {
+    if (!h) return -1;
+    GN_TRY
+    int rc = check_limits(h, batch, m, n, t);
+    if (rc) return rc;
+    if (!dJ) { h->err = "dJ is NULL"; return -6; }
+    if (!drx) { h->err = "drx is NULL"; return -9; }
+    if (t > 0 && (!dAt || !dcx)) { h->err = "dAt / dcx is NULL with t > 0"; return -10; }
+    return solve_chunked(h, batch, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, -1, -1, dp, db, dd,
+                         dinfo, (long long*)djpvtA, (long long*)djpvtL, (long long*)djpvtJ2, nullptr);
+    GN_CATCH(h)
 }
 
 static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, int64_t t, const double* J,
@@ -922,11 +1005,12 @@ static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, i
                       double* p, double* b, double* d, enlsip_gn_info* info, int64_t* jA, int64_t* jL, int64_t* jJ,
                       bool factored = false) {
     if (!h) return -1;
+    GN_TRY
     int rc = check_limits(h, batch, m, n, t);
     if (rc) return rc;
-    if (!J) return -6;
-    if (ldj < m) return -7;
-    if (!rx) return -9;
+    if (!J) { h->err = "J is NULL"; return -6; }
+    if (ldj < m) { h->err = "ldj < m"; return -7; }
+    if (!rx) { h->err = "rx is NULL"; return -9; }
     if (factored) {
         const Plan& P = h->plan;
         if (!(h->factors_valid && h->constraints_only && h->have_plan && P.batch == 1 && P.m == m && P.n == n && P.t == t)) {
@@ -934,9 +1018,13 @@ static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, i
             return -1;
         }
     } else {
-        if (t > 0 && (!At || !cx)) return -10;
-        if (t > 0 && ldat < n) return -11;
+        if (t > 0 && (!At || !cx)) { h->err = "At / cx is NULL with t > 0"; return -10; }
+        if (t > 0 && ldat < n) { h->err = "ldat < n"; return -11; }
     }
+    // truncation dimensions index the triangular factors: dimA <= min(n, t) = rows of F_L11.R, dimJ2 <= min(m, n) >= kp
+    // (the kernels clamp dimJ2 to kp = min(m, n - rankA), which is only known on the device)
+    if (dimA_ov > std::min(n, t)) { h->err = "dimA_override > min(n, t)"; return -16; }
+    if (dimJ2_ov > std::min(m, n)) { h->err = "dimJ2_override > min(m, n)"; return -17; }
     GN_HIP(hipSetDevice(h->device));
     const int kA = (int)std::min(n, t);
     // staging: inputs packed (ld = m / n), outputs packed
@@ -969,8 +1057,8 @@ static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, i
     GN_HIP(hipMemcpyAsync(drx, rx, (size_t)batch * m * 8, hipMemcpyHostToDevice, s));
     if (t > 0 && !factored) GN_HIP(hipMemcpyAsync(dcx, cx, (size_t)batch * t * 8, hipMemcpyHostToDevice, s));
     h->reuse_once = factored;      // A', cx (same staging slots) and the constraint factors are resident
-    rc = solve_dev(h, batch, m, n, t, dJ, m, m * n, drx, dAt, n, n * t, dcx, eps_rank, dimA_ov, dimJ2_ov, dp, db, dd,
-                   nullptr, djA, djL, djJ);
+    rc = solve_chunked(h, batch, m, n, t, dJ, m, m * n, drx, dAt, n, n * t, dcx, eps_rank, dimA_ov, dimJ2_ov, dp, db, dd,
+                       nullptr, djA, djL, djJ, info);
     if (rc) return rc;
     if (p) GN_HIP(hipMemcpyAsync(p, dp, (size_t)batch * n * 8, hipMemcpyDeviceToHost, s));
     if (b && t > 0) GN_HIP(hipMemcpyAsync(b, db, (size_t)batch * t * 8, hipMemcpyDeviceToHost, s));
@@ -979,12 +1067,8 @@ static int solve_host(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n, i
     if (jL && kA > 0) GN_HIP(hipMemcpyAsync(jL, djL, (size_t)batch * kA * 8, hipMemcpyDeviceToHost, s));
     if (jJ) GN_HIP(hipMemcpyAsync(jJ, djJ, (size_t)batch * n * 8, hipMemcpyDeviceToHost, s));
     GN_HIP(hipStreamSynchronize(s));
-    if (info)
-        for (int64_t k = 0; k < batch; ++k) {
-            const ProbState& st = h->h_state[k];
-            info[k] = {st.rankA, st.rankJ2, st.code, st.dimA, st.dimJ2, st.status};
-        }
     return 0;
+    GN_CATCH(h)
 }
 
 int enlsip_gn_factor_constraints(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const double* At, int64_t ldat,
@@ -996,6 +1080,7 @@ int enlsip_gn_factor_constraints(enlsip_gn_handle h, int64_t m, int64_t n, int64
     if (t > 0 && ldat < n) return -6;
     GN_HIP(hipSetDevice(h->device));
     h->split = 0;
+    h->chunk0 = 0;
     rc = make_plan(h, 1, m, n, t);
     if (rc) return rc;
     // same staging layout as solve_host, so that a following solve of the same shape reuses the buffers

@@ -90,7 +90,16 @@ struct enlsip_gn_context {
     long long pipeline_min = 128;       // smallest batch that is split
     long long split = 0;                // problems [split, batch) of the last solve live on `child` (0: not split)
     hipEvent_t ev_fork = nullptr;
+    long long chunk0 = 0;               // first problem (index in the caller's batch) of the resident chunk: batches above the launch limit run in chunks
     long long tsqr_n2 = -1;             // n2 of the last tsqr_local on this handle
+    // communicator of enlsip_gn_solve_tsqr: an RCCL communicator (created here or handed in) or the caller's all-gather
+    void* tsqr_comm = nullptr;
+    bool tsqr_comm_owned = false;
+    enlsip_gn_allgather_fn tsqr_xfn = nullptr;
+    void* tsqr_xctx = nullptr;
+    int tsqr_ranks = 1, tsqr_rank = 0;
+    gn::DevBuf xbuf;                    // send message + G received messages
+    float tsqr_ms[3] = {};              // local / exchange / combine of the last enlsip_gn_solve_tsqr (profiling on)
     int factor_waves = 8;   // waves per workgroup of k_caqr_factor (ENLSIP_GN_FACTOR_WAVES=4 / 16 select the 4- / 16-wave forms; measured slower)
     int qrcp_mode = 2;   // 0 persistent (co-resident workgroups), 1 one launch per pivot step, 2 blocked with verified pivots
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;

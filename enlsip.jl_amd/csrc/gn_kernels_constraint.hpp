@@ -114,7 +114,8 @@ __global__ __launch_bounds__(NTH) void k_constraint(ConstraintArgs a) {
     const int rankA = sh_i[1];
     int code = (rankA == t) ? 1 : -1;
     if (a.code_override != 0) code = a.code_override;
-    const int dimA = (a.dimA_override >= 0) ? a.dimA_override : rankA;
+    int dimA = (a.dimA_override >= 0) ? a.dimA_override : rankA;
+    dimA = dimA < kA ? dimA : kA;         // the host rejects larger overrides; never index past the factor
 
     // ---- L11 = R_A'  (t x kA, lower trapezoid) ---------------------------------------------
     const bool fl_lds = !a.fl_done && (size_t)t * kA <= (size_t)CMAT_DOUBLES;

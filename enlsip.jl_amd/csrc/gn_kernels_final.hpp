@@ -120,7 +120,8 @@ __global__ __launch_bounds__(NTH) void k_pivot_solve(FinalArgs a) {
         __syncthreads();
         rankJ2 = sh_i[1];
     }
-    const int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
+    int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
+    dimJ2 = dimJ2 < kp ? dimJ2 : kp;      // the host rejects larger overrides; never index past the factor
 
     // dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]
     for (int i = tid; i < n2; i += nt)

@@ -27,6 +27,9 @@ class Info(C.Structure):
                 ("dimA", C.c_int64), ("dimJ2", C.c_int64), ("status", C.c_int64)]
 
 
+# enlsip_gn_allgather_fn: int (*)(void* ctx, const void* dsend, void* drecv, size_t bytes_per_rank, void* hip_stream)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
 _i64 = C.c_int64
@@ -72,6 +75,13 @@ PROTOTYPES = {
                                            C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, _dp, _ip]),
     "enlsip_gn_tsqr_combine_dev": (C.c_int, [_h, _i64, _i64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                              C.c_void_p, _dp, C.POINTER(Info), C.c_void_p]),
+    "enlsip_gn_tsqr_unique_id": (C.c_int, [C.c_void_p]),
+    "enlsip_gn_tsqr_init_rccl": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_int]),
+    "enlsip_gn_tsqr_set_comm": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_int]),
+    "enlsip_gn_tsqr_set_exchange": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "enlsip_gn_solve_tsqr": (C.c_int, [_h, _i64, _i64, _i64, C.c_void_p, _i64, C.c_void_p, C.c_void_p, _i64, C.c_void_p,
+                                       C.c_double, C.c_void_p, C.c_void_p, _dp, C.POINTER(Info), C.c_void_p]),
+    "enlsip_gn_tsqr_get_stage_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "enlsip_gn_set_profiling": (C.c_int, [_h, C.c_int]),
     "enlsip_gn_get_stage_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "enlsip_gn_get_update_stats": (C.c_int, [_h, C.POINTER(C.c_float), _ip, _dp]),

@@ -18,9 +18,11 @@
  *                               first/second_lagrange_mult_estimate!, search_direction_analys,
  *                               choose_subspace_dimensions, determine_solving_dim consume
  *                                                     src/enlsip_functions.jl:461-537, 1118-1291
- *   enlsip_gn_tsqr_*            (new design, no reference counterpart) row-sharded J for
- *                               multi-GPU TSQR; the exchange itself is done by the caller
- *                               (RCCL all-gather), see INTEGRATION.md.
+ *   enlsip_gn_solve_tsqr        (new design, no reference counterpart) the same subproblem with the ROWS of one
+ *                               tall J sharded over the GPUs of a node: `JQ1 = J * F_A.Q` ... `qr(J2, ColumnNorm())`
+ *                               (src/enlsip_functions.jl:219-223) as a TSQR whose one exchange step is an RCCL
+ *                               all-gather over xGMI inside the library; enlsip_gn_tsqr_local_dev / _combine_dev are
+ *                               its two stages for callers that bring their own transport.  INTEGRATION.md section 5.
  *
  * Conventions
  *   - All matrices column-major (Julia / LAPACK layout), fp64, explicit leading dimensions.
@@ -46,6 +48,7 @@ extern "C" {
 #endif
 
 typedef struct enlsip_gn_context* enlsip_gn_handle;
+typedef int (*enlsip_gn_allgather_fn)(void* ctx, const void* dsend, void* drecv, size_t bytes_per_rank, void* hip_stream);
 
 /* which factorisation an accessor addresses */
 enum {
@@ -225,6 +228,35 @@ int enlsip_gn_tsqr_combine_dev(enlsip_gn_handle h, int64_t G, int64_t n2,
                                const double* dRstack, const double* dzstack, double eps_rank,
                                double* p, double* dlead, double* comb_tail_sq,
                                enlsip_gn_info* info, int64_t* jpvtJ2);
+
+/* ---- the same, as ONE collective call (every rank of the communicator calls it with its row block) -------------------------
+ *
+ * Communicator of a handle (default: one rank, no exchange).  Exactly one of:
+ *   enlsip_gn_tsqr_init_rccl     the library creates an RCCL communicator: rank 0 obtains 128 bytes from
+ *                                enlsip_gn_tsqr_unique_id, the caller hands them to every rank by whatever means it has (Julia:
+ *                                Distributed / MPI.jl; Python: torch.distributed broadcast), every rank calls init_rccl (collective,
+ *                                ncclCommInitRank).  The handle's device must be the rank's GPU.  RCCL is loaded at run time
+ *                                (librccl.so.1; ENLSIP_GN_RCCL_LIB overrides): the library has no link-time dependency on it.
+ *   enlsip_gn_tsqr_set_comm      an existing ncclComm_t of the caller (not destroyed by the library); NULL = back to one rank.
+ *   enlsip_gn_tsqr_set_exchange  any other transport: fn(ctx, dsend, drecv, bytes_per_rank, hip_stream) must all-gather
+ *                                bytes_per_rank bytes of DEVICE memory from every rank into drecv (rank-major) and return 0 once
+ *                                drecv is complete or the transfer is enqueued on hip_stream; dsend is complete when fn is called.
+ *
+ * enlsip_gn_solve_tsqr: rank g passes its m_loc rows of J and rx (device pointers; the row blocks may have different heights)
+ * and the replicated At, cx.  One message per rank travels: the packed upper triangle of the local R (8 n2 (n2 + 1) / 2 bytes:
+ * 4.2 MB at n2 = 1024), z = (Q_loc' d_loc)[1:n2] and the squared norm of the local tail.  Every rank returns the same HOST
+ * outputs: p (n), dlead (n2 <= n entries: leading entries of F_J2.Q' d), d_norm = ||d||_2 over all ranks, info, jpvtJ2 (n2 <= n).
+ */
+int enlsip_gn_tsqr_unique_id(void* id128);
+int enlsip_gn_tsqr_init_rccl(enlsip_gn_handle h, const void* id128, int nranks, int rank);
+int enlsip_gn_tsqr_set_comm(enlsip_gn_handle h, void* nccl_comm, int nranks, int rank);
+int enlsip_gn_tsqr_set_exchange(enlsip_gn_handle h, enlsip_gn_allgather_fn fn, void* ctx, int nranks, int rank);
+int enlsip_gn_solve_tsqr(enlsip_gn_handle h, int64_t m_loc, int64_t n, int64_t t,
+                         const double* dJ, int64_t ldj, const double* drx,
+                         const double* dAt, int64_t ldat, const double* dcx, double eps_rank,
+                         double* p, double* dlead, double* d_norm, enlsip_gn_info* info, int64_t* jpvtJ2);
+/* local / exchange / combine time (ms, HIP events) of the last enlsip_gn_solve_tsqr with profiling enabled */
+int enlsip_gn_tsqr_get_stage_ms(enlsip_gn_handle h, float* ms3);
 
 /* ---- instrumentation: HIP-event time (ms) of the stages of the last solve ------------------ */
 enum {

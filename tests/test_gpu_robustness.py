@@ -91,14 +91,44 @@ def test_bench_two_rank_control_flow_rehearsal():
     env = dict(os.environ, ENLSIP_BENCH_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "32", "--cpu-budget", "0"]      # (torchrun's own parser trips over --m / --n / --t: default C2 shape)
+           "--batch", "32", "--cpu-budget", "0"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                  # rank 0 only
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["results_check"]["finite"]
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["results_check"]["finite_and_within_tolerance"]
+    assert rec["results_check"]["problems_checked"] == 32 and rec["config"]["name"] == "C2"
+    assert rec["metric"] == "GN subproblem solves/sec at (m=4096,n=512); achieved fraction of HBM roofline"
     assert rec["value"] > 0 and rec["cpu_baseline"] is None and rec["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["C5", "C4"])
+def test_bench_starts_its_own_ranks(config):
+    """`python bench.py --gpus 2 --config ...` with no launcher around it: the script starts its two ranks itself (before it
+    touches the GPU) and rank 0 prints the one line.  C5: the ranks own consecutive shards of problems; C4: the ranks own row
+    blocks of ONE 262144 x 1024 problem and the library's TSQR collective runs over its caller-supplied transport (gloo through
+    host memory here; RCCL when every rank has its own GPU)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ENLSIP_BENCH_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--steps", "2", "--warmup", "1",
+           "--cpu-budget", "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["name"] == config and rec["results_check"]["finite_and_within_tolerance"]
+    if config == "C5":
+        assert rec["scaling"] == "weak" and rec["metric"].startswith("GN subproblem solves/sec at (m=256,n=32)")
+        assert rec["results_check"]["problems_checked"] == 8192 and rec["roofline"]["bound"] == "hbm"
+    else:
+        assert rec["scaling"] == "strong" and rec["metric"].startswith("GN subproblem solves/sec at (m=262144,n=1024)")
+        assert rec["results_check"]["rankJ2"] == 1024 and rec["roofline"]["bound"] == "mfma"
+        assert rec["stage_ms"]["local"] > 0 and rec["stage_ms"]["combine"] > 0
 
 
 @pytest.mark.gpu
@@ -133,6 +163,15 @@ def test_raw_abi_rejects_bad_arguments_without_touching_the_device():
         rc = solve(**bad)
         assert rc < 0, (bad, rc)
         assert lib.enlsip_gn_last_error(h)                      # a message, not an empty string
+    # truncation dimensions beyond the triangular factors (they index LDS vectors and factor columns in the kernels)
+    for dA, dJ in ((t + 1, -1), (-1, min(m, n) + 1), (10 ** 9, -1), (-1, 10 ** 9)):
+        rc = lib.enlsip_gn_solve(h, m, n, t, fp(Jf), m, fp(rx), fp(At), n, fp(cx), SQRT_EPS, dA, dJ, fp(p), fp(b), fp(d),
+                                 C.byref(info), fp(jA), fp(jL), fp(jJ))
+        assert rc < 0 and b"override" in lib.enlsip_gn_last_error(h), (dA, dJ, rc)
+    # a dimJ2 override between kp = min(m, n - rankA) and min(m, n) passes the host check and is clamped on the device
+    rc = lib.enlsip_gn_solve(h, m, n, t, fp(Jf), m, fp(rx), fp(At), n, fp(cx), SQRT_EPS, -1, n, fp(p), fp(b), fp(d),
+                             C.byref(info), fp(jA), fp(jL), fp(jJ))
+    assert rc == 0 and info.dimJ2 == n - t
     assert solve() == 0                                         # and the handle still works
     ref = go.gn_subproblem(J, rx, A, cx)
     assert np.linalg.norm(p - ref.p) <= 1e-11 * np.linalg.norm(ref.p)
@@ -151,12 +190,48 @@ def test_raw_abi_rejects_bad_arguments_without_touching_the_device():
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_tsqr_driver_with_real_ranks_on_the_device(world):
-    """enlsip_gn.tsqr.tsqr_solve as a real collective: `world` processes, each with its own handle and row block on the GPU
-    (tests/tsqr_rank_worker.py), gloo between them on this one-GPU box; every rank must reproduce the oracle's single solve."""
+    """The library's collective enlsip_gn_solve_tsqr (and the two-stage form behind enlsip_gn.tsqr.tsqr_solve) with real ranks:
+    `world` processes, each with its own handle and row block on the GPU (tests/tsqr_rank_worker.py); on this one-GPU box the
+    exchange runs over the caller-supplied transport (gloo through host memory — RCCL refuses two ranks on one device); every
+    rank must reproduce the oracle's single solve."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(29540 + world), os.path.join(root, "tests", "tsqr_rank_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
-    assert out.stdout.count(" ok") == 3 * world and "FAIL" not in out.stdout
+    assert out.stdout.count(" ok") == 2 * 3 * world and "FAIL" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_solve_tsqr_through_a_one_rank_rccl_communicator():
+    """The RCCL leg of enlsip_gn_solve_tsqr on the one GPU there is: unique id, ncclCommInitRank with one rank, ncclAllGather on
+    the handle's stream — against the oracle.  (More ranks need one GPU each: tests/tsqr_rank_worker.py with TSQR_BACKEND=nccl.)"""
+    import ctypes as C
+    import torch
+    from enlsip_gn import GNSolver
+    from enlsip_gn.tsqr import tsqr_solve_lib, tsqr_stage_ms
+    s = GNSolver(device=0)
+    try:
+        ident = C.create_string_buffer(128)
+        assert s._lib.enlsip_gn_tsqr_unique_id(ident) == 0
+        s._chk(s._lib.enlsip_gn_tsqr_init_rccl(s._h, ident, 1, 0))
+        dev = torch.device("cuda", 0)
+        for (m, n, t) in [(5000, 96, 7), (3000, 300, 0)]:
+            J, rx, A, cx = synth.make_problem(7700 + m, m, n, t)
+            ref = go.gn_subproblem(J, rx, A, cx)
+            Jd = torch.tensor(np.ascontiguousarray(J.T), dtype=torch.float64, device=dev)
+            rd = torch.tensor(rx, dtype=torch.float64, device=dev)
+            Ad = torch.tensor(np.ascontiguousarray(A), dtype=torch.float64, device=dev) if t else None
+            cd = torch.tensor(cx, dtype=torch.float64, device=dev) if t else None
+            torch.cuda.synchronize()
+            s.set_profiling(True)
+            out = tsqr_solve_lib(s, Jd, rd, Ad, cd)
+            s.set_profiling(False)
+            assert rel(out.p, ref.p) <= 1e-11 and (out.rankA, out.rankJ2) == (ref.rankA, ref.rankJ2)
+            assert np.array_equal(out.jpvtJ2, ref.jpvtJ2)
+            assert abs(out.d_norm - np.linalg.norm(ref.d)) <= 1e-12 * np.linalg.norm(ref.d)
+            ms = tsqr_stage_ms(s)
+            assert ms["local"] > 0 and ms["combine"] > 0
+    finally:
+        s.close()
