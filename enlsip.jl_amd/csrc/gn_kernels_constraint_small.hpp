@@ -72,7 +72,8 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_CS_OCC) ? ENLSIP_CS_OCC : (
     const int rankA = wave_pseudo_rank(dg, kA, a.eps_rank, ln);
     int code = (rankA == t) ? 1 : -1;
     if (a.code_override != 0) code = a.code_override;
-    const int dimA = (a.dimA_override >= 0) ? a.dimA_override : rankA;
+    int dimA = (a.dimA_override >= 0) ? a.dimA_override : rankA;
+    dimA = dimA < kA ? dimA : kA;         // as k_constraint: never past the factor
 
     // b_buff = -cx[F_A.p]   (lane i: entry i)
     const double bb = (ln < t) ? -cx[lp] : 0.0;

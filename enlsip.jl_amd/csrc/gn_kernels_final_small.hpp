@@ -91,7 +91,8 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : (
     const int lp = (ln <= n2) ? lpos[ln] : 0;
     wave_qrcp_store_upper(q, ln, lp, n2 + 1, Rt, ldr);
     const int rankJ2 = wave_pseudo_rank(dg, kp, a.eps_rank, ln);
-    const int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
+    int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
+    dimJ2 = dimJ2 < kp ? dimJ2 : kp;      // as k_pivot_solve: never past the factor
     GN_PS_STAMP(3);
 
     // ---- dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]: lane r carries row r of the right-hand side ------------------------
