@@ -25,7 +25,6 @@
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_lagrange.hpp"
 #include "gn_kernels_qrcp_dist.hpp"
-#include "gn_kernels_qrcp_persist.hpp"
 #include "gn_kernels_qrcp_block.hpp"
 #include "gn_kernels_qrcp_block_reg.hpp"
 
@@ -168,7 +167,7 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     h->qdCand = (void*)p; p += (size_t)batch * P.sCand * sizeof(QdCand);
     h->state = (ProbState*)p;
     p += (((size_t)batch * sizeof(ProbState) + 255) / 256) * 256;
-    h->abort_word = (unsigned*)p;
+    h->small = (unsigned*)p;        // 256 bytes of scalars (tail sums of the TSQR stages)
     p += 256;
     h->sbInfo = (void*)p;
     p += (((size_t)batch * sizeof(SbInfo) + 255) / 256) * 256;
@@ -251,11 +250,8 @@ static CaqrArgs caqr_args(enlsip_gn_handle h, int k, const LevelPlan& L) {
 static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
     dim3 grid(groups, (unsigned)h->plan.batch);
     // one-tile problems of at most 256 rows: 4 waves x 8 columns issue ~20 % fewer instructions per step than 8 x 4
-    // (measured on C5: panel stage 0.63 -> 0.57 ms); everywhere else the 8-wave form wins
-    const bool four = (h->factor_waves != 8) || (h->plan.m <= 256 && !getenv("ENLSIP_GN_FACTOR_WAVES"));
-    if (h->factor_waves == 16 && h->plan.RPL == 8) {
-        hipLaunchKernelGGL((k_caqr_factor<8, 16>), grid, dim3(1024), 0, h->stream, a);
-    } else if (!four) {
+    // (measured on C5: panel stage 0.63 -> 0.57 ms); everywhere else the 8-wave form wins (a 16-wave form: 8.1 -> 11.2 ms)
+    if (h->plan.m > 256) {
         if (h->plan.RPL == 8) hipLaunchKernelGGL((k_caqr_factor<8, 8>), grid, dim3(512), 0, h->stream, a);
         else hipLaunchKernelGGL((k_caqr_factor<4, 8>), grid, dim3(512), 0, h->stream, a);
     } else {
@@ -295,7 +291,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         const int bwk = std::min(PB, kp_launch - k * PB);
         const int ntrail = n2_launch + 1 - (k * PB + bwk);  // trailing columns incl. the augmented one
         // last panel narrower than 32 with d as the only trailing column: d rides through the factor kernels
-        const bool passenger = (ntrail == 1 && bwk < PB && kp_launch == n2_launch && !getenv("ENLSIP_GN_NO_PASSENGER"));
+        const bool passenger = (ntrail == 1 && bwk < PB && kp_launch == n2_launch);
         for (const LevelPlan& L : P.panels[k].levels) {
             CaqrArgs a = caqr_args(h, k, L);
             a.npass = passenger ? 1 : 0;
@@ -358,7 +354,6 @@ static int run_qrcp_dist(enlsip_gn_handle h, int n2_launch) {
 }
 
 // blocked pivoted QR of R0 with verified pivots (gn_kernels_qrcp_block.hpp)
-static inline bool big_kp(int kp) { return kp > 512; }
 static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     const Plan& P = h->plan;
     const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
@@ -374,25 +369,12 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     q.n2cap = n2_launch;
     a.info = (SbInfo*)h->sbInfo; a.inblk = h->sbInblk; a.sIn = P.sQI; a.blkid = 0;
     a.Tsb = h->sbT; a.sTsb = PB * PB; a.act = h->sbAct; a.sAct = P.sQI + 32;
-    const bool blk_update = !big_kp(kp_launch) && !getenv("ENLSIP_GN_SB_STEPWISE");   // MFMA block update (kp <= 512)
-    if (!blk_update) { a.Tsb = nullptr; a.act = nullptr; }
-    const bool reg_factor = !big_kp(kp_launch) && !getenv("ENLSIP_GN_SB_LDS");   // candidates in registers (kp <= 512)
     a.dbg = nullptr;
-    if (getenv("ENLSIP_GN_SB_DEBUG")) {   // diagnostic: per-block phase stamps of problem 0 into the scratch buffer
-        if (grow(h, h->scratch, 8 * 8 * 1024) == 0) {
-            a.dbg = (long long*)h->scratch.p;
-            (void)hipMemsetAsync(a.dbg, 0, 8 * 8 * 1024, h->stream);
-        }
-    }
     const int G = (n2_launch + 1 + QD_CPW - 1) / QD_CPW;
     dim3 grid(G, (unsigned)P.batch);
-    const bool big = kp_launch > 512;
     hipStream_t s = h->stream;
-    if (big) hipLaunchKernelGGL(k_qd_init<16>, grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, s, q);
     hipLaunchKernelGGL(k_sb_reset, dim3(((unsigned)P.n + 255) / 256, (unsigned)P.batch), dim3(256), 0, s, a, (int)P.n);
-    const size_t lds = sizeof(SbLds);
-    if (big) big_lds(k_sb_factor<16>, lds); else big_lds(k_sb_factor<8>, lds);
     dim3 ugrid((n2_launch + 1 + SB_UCW - 1) / SB_UCW, (unsigned)P.batch);
     int it = 0;
     // blocks of <= 32 steps; the first chunk is sized from the previous solve on this handle (one host check per
@@ -403,17 +385,11 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
         for (int i = 0; i < chunk && it < kp_launch; ++i, ++it) {
             a.blkid = it;
             GN_TRACE(h, "  qrcp block %d", it);
-            if (big) {
-                hipLaunchKernelGGL(k_sb_factor<16>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
-                hipLaunchKernelGGL(k_sb_update<16>, ugrid, dim3(256), 0, s, a);
-            } else {
-                if (!reg_factor) hipLaunchKernelGGL(k_sb_factor<8>, dim3((unsigned)P.batch), dim3(1024), lds, s, a);
-                else if (kp_launch <= 256) hipLaunchKernelGGL((k_sb_factor_reg<4, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
-                else if (kp_launch <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
-                else hipLaunchKernelGGL((k_sb_factor_reg<8, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
-                if (blk_update) hipLaunchKernelGGL(k_sb_update_blk, ugrid, dim3(256), 0, s, a);
-                else hipLaunchKernelGGL(k_sb_update<8>, ugrid, dim3(256), 0, s, a);
-            }
+            // candidates in the registers of one workgroup (kp <= 512), block reflector applied to the still-active columns
+            if (kp_launch <= 256) hipLaunchKernelGGL((k_sb_factor_reg<4, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
+            else if (kp_launch <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((k_sb_factor_reg<8, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
+            hipLaunchKernelGGL(k_sb_update_blk, ugrid, dim3(256), 0, s, a);
         }
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(hinfo, h->sbInfo, (size_t)P.batch * sizeof(SbInfo), hipMemcpyDeviceToHost, s));
@@ -431,52 +407,6 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
         chunk = 4;
     }
     hipLaunchKernelGGL(k_qd_assemble, grid, dim3(256), 0, s, q);
-    GN_HIP(hipGetLastError());
-    if (a.dbg) {
-        std::vector<long long> hd(8 * 64);
-        GN_HIP(hipMemcpyAsync(hd.data(), a.dbg, hd.size() * 8, hipMemcpyDeviceToHost, s));
-        GN_HIP(hipStreamSynchronize(s));
-        for (int b = 0; b < 64 && hd[b * 8] != 0; ++b)
-            fprintf(stderr, "sb block %2d: steps %3lld | keys+rank %6.2f us, load %6.2f, steps %7.2f, flush %5.2f, writeback-start %5.2f\n", b, hd[b * 8 + 5],
-                    (hd[b * 8 + 1] - hd[b * 8]) * 0.01, (hd[b * 8 + 2] - hd[b * 8 + 1]) * 0.01, (hd[b * 8 + 3] - hd[b * 8 + 2]) * 0.01,
-                    (hd[b * 8 + 4] - hd[b * 8 + 3]) * 0.01, 0.0);
-    }
-    return 0;
-}
-
-// persistent LDS-resident pivoted QR of R0: G co-resident workgroups per problem, chunks of problems
-static int run_qrcp_persist(enlsip_gn_handle h, int n2_launch) {
-    const Plan& P = h->plan;
-    const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
-    const int ctot = n2_launch + 1;
-    const int kp_pad = (kp_launch + 1) & ~1;
-    const size_t slab_budget = 120 * 1024;
-    int cw_max = (int)(slab_budget / ((size_t)kp_pad * 8));
-    cw_max &= ~1;
-    if (cw_max < 2) return -1;
-    int G = (ctot + cw_max - 1) / cw_max;
-    int CW = (ctot + G - 1) / G;
-    CW = (CW + 1) & ~1;
-    if (G > 64 || 2 * G > (int)P.n + 1 || G > P.qdGmax) return -1;   // header poll uses one wave; xbuf reuses qdM
-    const size_t lds = ((size_t)CW * kp_pad + 2 * CW) * 8 + ((size_t)CW + 8) * 4 + 16;
-    const int per_launch = std::max(1, h->cu_count / G);
-    QpArgs a{};
-    a.n = (int)P.n; a.ldw = P.ldw; a.ldr = P.ldr; a.G = G; a.CW = CW; a.kp_pad = kp_pad;
-    a.W = h->W; a.sW = P.sW; a.Rt = h->Rt; a.sRt = P.sRt; a.tau = h->tauJ; a.sTau = P.sTauJ;
-    a.jpvt = h->jpvtJ; a.sJ = P.sJJ; a.hdr = (QpHeader*)h->qdCand; a.sHdr = P.sCand;
-    a.xbuf = h->qdM; a.sX = P.sM; a.abort_word = h->abort_word; a.state = h->state; a.spin_limit = 1 << 20;
-    a.n2cap = n2_launch;
-    GN_HIP(hipMemsetAsync(h->qdCand, 0, (size_t)P.batch * P.sCand * sizeof(QpHeader), h->stream));
-    GN_HIP(hipMemsetAsync(h->abort_word, 0, 16, h->stream));
-    const bool big = kp_launch > 512;
-    if (big) big_lds(k_qrcp_persist<16>, lds); else big_lds(k_qrcp_persist<8>, lds);
-    for (int p0 = 0; p0 < (int)P.batch; p0 += per_launch) {
-        const int np = std::min(per_launch, (int)P.batch - p0);
-        a.prob0 = p0;
-        dim3 grid(G, np);
-        if (big) hipLaunchKernelGGL(k_qrcp_persist<16>, grid, dim3(256), lds, h->stream, a);
-        else hipLaunchKernelGGL(k_qrcp_persist<8>, grid, dim3(256), lds, h->stream, a);
-    }
     GN_HIP(hipGetLastError());
     return 0;
 }
@@ -564,27 +494,30 @@ static int run_constraint_dist(enlsip_gn_handle h, ConstraintArgs ca, long long 
 }
 
 // F_A, rankA, F_L11, b, p1, block T of Q1 for every problem of the batch (plan already made)
+// prob0 / code_ov: the re-solve of ONE resident problem (enlsip_gn_resolve) takes the same route as the solve that produced its
+// factors, so that they are rewritten bit for bit by the same kernels.
 static int run_constraint_stage(enlsip_gn_handle h, long long batch, long long m, long long n, long long t, const double* dAt,
-                                long long ldat, long long strideAt, const double* dcx, double eps_rank, long long dimA_ov) {
+                                long long ldat, long long strideAt, const double* dcx, double eps_rank, long long dimA_ov,
+                                int prob0 = 0, int code_ov = 0) {
     const Plan& P = h->plan;
     hipStream_t s = h->stream;
-    h->cdist.valid = false;
+    if (prob0 == 0 && code_ov == 0) h->cdist.valid = false;
     ConstraintArgs ca{};
     ca.n = (int)n; ca.t = (int)t; ca.kA = P.kA; ca.m = (int)m; ca.eps_rank = eps_rank;
-    ca.dimA_override = (int)dimA_ov; ca.code_override = 0;
+    ca.dimA_override = (int)dimA_ov; ca.code_override = code_ov; ca.prob0 = prob0;
     ca.At = dAt; ca.ldat = ldat; ca.strideAt = strideAt; ca.cx = dcx; ca.stride_cx = t;
     ca.FA = h->FA; ca.sFA = P.sFA; ca.tauA = h->tauA; ca.sTauA = P.sTauA; ca.jpvtA = h->jpvtA; ca.sJA = P.sJA;
     ca.FL = h->FL; ca.sFL = P.sFL; ca.tauL = h->tauL; ca.sTauL = P.sTauL; ca.jpvtL = h->jpvtL; ca.sJL = P.sJL;
     ca.TA = h->TA; ca.sTA = P.sTA; ca.p1 = h->p1; ca.sP1 = P.sP1; ca.bvec = h->bvec; ca.sB = P.sB;
     ca.state = h->state;
     // many constraints: both factorisations through the distributed pivoted QR
-    if (t > 64 && (size_t)n * t > (size_t)CMAT_DOUBLES && !getenv("ENLSIP_GN_FA_L2")) return run_constraint_dist(h, ca, batch, n, t);
+    if (t > 64 && (size_t)n * t > (size_t)CMAT_DOUBLES) return run_constraint_dist(h, ca, batch, n, t);
     // F_A of a matrix that does not fit the LDS area of k_constraint: whole matrix in registers (gn_kernels_geqp3_reg.hpp)
-    if (t >= 1 && t <= 64 && n <= 512 && (size_t)n * t > (size_t)CMAT_DOUBLES && !getenv("ENLSIP_GN_FA_L2")) {
+    if (t >= 1 && t <= 64 && n <= 512 && (size_t)n * t > (size_t)CMAT_DOUBLES) {
         Geqp3RegArgs ga{};
         ga.rows = (int)n; ga.cols = (int)t; ga.A = dAt; ga.lda = ldat; ga.strideA = strideAt;
         ga.F = h->FA; ga.sF = P.sFA; ga.tau = h->tauA; ga.sTau = P.sTauA; ga.jpvt = h->jpvtA; ga.sJ = P.sJA;
-        ga.T = h->TA; ga.sT = P.sTA; ga.prob0 = 0;
+        ga.T = h->TA; ga.sT = P.sTA; ga.prob0 = prob0;
         if (n <= 256) hipLaunchKernelGGL(k_geqp3_reg<4>, dim3((unsigned)batch), dim3(512), 0, s, ga);
         else hipLaunchKernelGGL(k_geqp3_reg<8>, dim3((unsigned)batch), dim3(512), 0, s, ga);
         ca.fa_done = 1;
@@ -654,7 +587,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         qa.VT = (P.sM >= (long long)n * KBLK) ? h->qdM : nullptr; qa.sVT = P.sM;
         if (h->flags & ENLSIP_GN_UPDATE_REFLECTORS) launch_jq1(qa, (int)batch, s);   // plain-FMA A/B partner
         else if (launch_jq1_rows(qa, (int)batch, s)) {}                             // small n, few reflectors
-        else if (getenv("ENLSIP_GN_JQ1_V1") || !launch_jq1_v2(qa, (int)batch, s)) launch_jq1_mfma(qa, (int)batch, s);
+        else if (!launch_jq1_v2(qa, (int)batch, s)) launch_jq1_mfma(qa, (int)batch, s);      // regular shapes / general shapes
         mark(2);
         GN_TRACE(h, "attempt %d n2_launch=%d: J*Q1 done", attempt, n2_launch);
         // 3. CAQR of [J2 | d]
@@ -678,19 +611,10 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         {
             const int kp_launch = (int)std::min<long long>(m, n2_launch);
             if ((size_t)kp_launch * (n2_launch + 1) > (size_t)CMAT_DOUBLES) {
-                if (h->qrcp_mode == 2) {
-                    // more than 512 rows do not fit the register form of the blocked factorisation; its LDS-slab form
-                    // (16 candidates, ~13 steps per block, 14 us per step) loses to one launch per pivot step (6.5 us)
-                    rc = (kp_launch > 512 && !getenv("ENLSIP_GN_SB_LDS")) ? run_qrcp_dist(h, n2_launch) : run_qrcp_block(h, n2_launch);
-                    if (rc) return rc;
-                } else {
-                    rc = (h->qrcp_mode == 0) ? run_qrcp_persist(h, n2_launch) : -1;
-                    if (rc > 0) return rc;
-                    if (rc < 0) {   // shape not supported by the persistent kernel (or it is disabled)
-                        rc = run_qrcp_dist(h, n2_launch);
-                        if (rc) return rc;
-                    }
-                }
+                // more than 512 rows do not fit the register form of the blocked factorisation: one launch per pivot step
+                // (6.5 us per step; an LDS-slab blocked form was measured at 14 us per step and is gone)
+                rc = (kp_launch > 512) ? run_qrcp_dist(h, n2_launch) : run_qrcp_block(h, n2_launch);
+                if (rc) return rc;
                 fa.refactor = 2;
             }
         }
@@ -703,16 +627,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
         GN_HIP(hipStreamSynchronize(s));
         int n2max = 0;
-        bool aborted = false;
-        for (long long k = 0; k < batch; ++k) {
-            n2max = std::max(n2max, h->h_state[k].n2);
-            aborted = aborted || (h->h_state[k].status & 4);
-        }
-        if (aborted && h->qrcp_mode == 0) {   // co-residency was not granted in time: use the launch-per-step form
-            h->qrcp_mode = 1;
-            --attempt;
-            continue;
-        }
+        for (long long k = 0; k < batch; ++k) n2max = std::max(n2max, h->h_state[k].n2);
         if (n2max <= n2_launch) break;
         n2_launch = n2max;  // some A was rank deficient: J2 is wider than speculated, redo from J*Q1
     }
@@ -797,15 +712,6 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             h->cu_count = prop.multiProcessorCount;
-        const char* qm = getenv("ENLSIP_GN_QRCP");
-        // ENLSIP_GN_QRCP=persist selects the co-resident LDS kernel; default: one launch per pivot step
-        // (measured faster on MI355X for both batch = 1 and batch = 32, profiles/r1_notes.md)
-        h->qrcp_mode = 2;                                    // default: blocked with verified pivots
-        if (qm && qm[0] == 'p') h->qrcp_mode = 0;            // persist
-        if (qm && qm[0] == 's') h->qrcp_mode = 1;            // step: one launch per pivot step
-        const char* fw = getenv("ENLSIP_GN_FACTOR_WAVES");   // 4 or 8 waves per panel-factor workgroup (A/B switch)
-        if (fw && fw[0] == '4') h->factor_waves = 4;
-        if (fw && fw[0] == '1' && fw[1] == '6') h->factor_waves = 16;
         h->trace = getenv("ENLSIP_GN_TRACE") != nullptr;
         const char* pl = getenv("ENLSIP_GN_PIPELINE");       // 0: never split a batch over two streams
         if (pl && pl[0] == '0') h->pipeline = false;
@@ -916,8 +822,6 @@ static int solve_launchable(enlsip_gn_handle h, int64_t batch, int64_t m, int64_
             int rc = enlsip_gn_create(&h->child, &o);
             if (rc) { h->err = "could not create the second pipeline handle"; return rc; }
             h->child->pipeline = false;
-            h->child->qrcp_mode = h->qrcp_mode;
-            h->child->factor_waves = h->factor_waves;
         }
         if (!h->ev_fork) GN_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         GN_HIP(hipEventRecord(h->ev_fork, h->stream));

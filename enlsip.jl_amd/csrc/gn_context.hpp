@@ -72,7 +72,7 @@ struct enlsip_gn_context {
            *vec = nullptr, *qdM = nullptr, *qdVb = nullptr, *qdDiag = nullptr, *qdVn1 = nullptr, *qdVn2 = nullptr;
     int *qdChosen = nullptr, *qdPos = nullptr, *qdColat = nullptr;
     void* qdCand = nullptr;
-    unsigned* abort_word = nullptr;
+    unsigned* small = nullptr;
     int sb_hint = 0;             // blocks the previous blocked QRCP needed (+1): size of the first launch chunk
     double* sbT = nullptr;       // per problem: T factor of the current QRCP block (32 x 32)
     void* sbInfo = nullptr;      // SbInfo per problem (device)
@@ -100,8 +100,6 @@ struct enlsip_gn_context {
     int tsqr_ranks = 1, tsqr_rank = 0;
     gn::DevBuf xbuf;                    // send message + G received messages
     float tsqr_ms[3] = {};              // local / exchange / combine of the last enlsip_gn_solve_tsqr (profiling on)
-    int factor_waves = 8;   // waves per workgroup of k_caqr_factor (ENLSIP_GN_FACTOR_WAVES=4 / 16 select the 4- / 16-wave forms; measured slower)
-    int qrcp_mode = 2;   // 0 persistent (co-resident workgroups), 1 one launch per pivot step, 2 blocked with verified pivots
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
     gn::ProbState* state = nullptr;
     // staging for the host-pointer API

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_CS_OCC) ? ENLSIP_CS_OCC : (
 
 // Returns false when the shape is outside the kernel's range (the caller uses k_constraint).
 inline bool launch_constraint_small(int batch, hipStream_t s, const ConstraintArgs& a) {
-    if (a.n > 64 || a.t > 63 || a.fa_done || getenv("ENLSIP_GN_CONSTRAINT_WG")) return false;
+    if (a.n > 64 || a.t > 63 || a.fa_done) return false;
     const size_t lds = constraint_small_lds_bytes(a.kA);
     if (a.n <= 32 && a.t <= 32) hipLaunchKernelGGL(k_constraint_small<32>, dim3(batch), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(k_constraint_small<64>, dim3(batch), dim3(64), lds, s, a);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : (
 
 // Returns false when the launch shape is outside the kernel's range (the caller uses k_pivot_solve).
 inline bool launch_pivot_small(int kp_launch, int n2_launch, int batch, hipStream_t s, FinalArgs a) {
-    if (kp_launch > 64 || n2_launch + 1 > 64 || a.refactor != 1 || a.dsrc || getenv("ENLSIP_GN_PIVOT_WG")) return false;
+    if (kp_launch > 64 || n2_launch + 1 > 64 || a.refactor != 1 || a.dsrc) return false;
     const long long mx = a.n > a.t ? a.n : a.t;
     a.nv = (int)((mx + 7) / 8 * 8);
     a.matd = (kp_launch > 0 ? kp_launch : 1) * 65 + 1;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, (NMAX == 32 && ENLSIP_JR_OCC) ? ENLSIP_JR_OCC 
 
 // Returns false when the shape is outside this kernel's range (the caller falls through to the compact-WY kernels).
 inline bool launch_jq1_rows(const JQ1Args& a, int batch, hipStream_t s) {
-    if (a.n > 64 || a.kA > Q1R_MAXK || getenv("ENLSIP_GN_JQ1_NOROWS")) return false;
+    if (a.n > 64 || a.kA > Q1R_MAXK) return false;
     const dim3 grid((a.ldw + 255) / 256, batch);
     if (a.n <= 32) hipLaunchKernelGGL(k_jq1_rows<32>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_jq1_rows<64>, grid, dim3(256), 0, s, a);

@@ -346,19 +346,16 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
 inline bool launch_jq1_v2(const JQ1Args& a, int batch, hipStream_t s) {
     if (a.n > 512 || a.n % 128 != 0 || a.m % 32 != 0 || a.kA != KBLK) return false;
     if ((a.ldj & 1) || (a.strideJ & 1) || ((size_t)a.J & 15)) return false;
-    // NP = 2 (32 rows per workgroup) measured 3.9 ms on the C2 batch of 256, NP = 1 4.3 ms, the first form 4.2 ms;
-    // ENLSIP_GN_JQ1_ROWS=16 selects NP = 1
-    const char* rv = getenv("ENLSIP_GN_JQ1_ROWS");
-    const bool np2 = !(rv && rv[0] == '1');
+    // NP = 2 (32 rows per workgroup) measured 3.9 ms on the C2 batch of 256, NP = 1 4.3 ms, the first form 4.2 ms
     if (!a.VT) return false;
     hipLaunchKernelGGL(k_vt, dim3((a.n + 63) / 64, batch), dim3(256), 0, s, a);
-    dim3 grid(a.m / (np2 ? 32 : 16), batch);
+    dim3 grid(a.m / 32, batch);
     dim3 blk(256);
     switch (a.n / 128) {
-        case 1: if (np2) hipLaunchKernelGGL((k_jq1_v2<2, 4, 2>), grid, blk, 0, s, a); else hipLaunchKernelGGL((k_jq1_v2<2, 4, 1>), grid, blk, 0, s, a); break;
-        case 2: if (np2) hipLaunchKernelGGL((k_jq1_v2<4, 4, 2>), grid, blk, 0, s, a); else hipLaunchKernelGGL((k_jq1_v2<4, 4, 1>), grid, blk, 0, s, a); break;
-        case 3: if (np2) hipLaunchKernelGGL((k_jq1_v2<6, 4, 2>), grid, blk, 0, s, a); else hipLaunchKernelGGL((k_jq1_v2<6, 4, 1>), grid, blk, 0, s, a); break;
-        default: if (np2) hipLaunchKernelGGL((k_jq1_v2<8, 4, 2>), grid, blk, 0, s, a); else hipLaunchKernelGGL((k_jq1_v2<8, 4, 1>), grid, blk, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_jq1_v2<2, 4, 2>), grid, blk, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_jq1_v2<4, 4, 2>), grid, blk, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_jq1_v2<6, 4, 2>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_jq1_v2<8, 4, 2>), grid, blk, 0, s, a); break;
     }
     return true;
 }

@@ -11,13 +11,13 @@
 //     their norms (dlaqp2 rule), and the dot products with the columns retired earlier in the block are the Gram
 //     entries of the block's T factor — no separate pass over the reflectors.
 // Pivot rule, certainty test against the best outside norm, logical positions and the write-back are those of
-// the first form (same SbLds bookkeeping arrays; the slab is simply unused).
+// the first form (same bookkeeping arrays, no slab).
 #pragma once
 #include "gn_kernels_qrcp_block.hpp"
 
 namespace gn {
 
-struct SbRegLds {             // everything of SbLds except the slab
+struct SbRegLds {             // bookkeeping of a block: keys, positions, candidates, the block's Gram / T entries
     double valk[SB_NMAX];
     int posk[SB_NMAX];
     int pos_l[SB_NMAX];

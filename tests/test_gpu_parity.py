@@ -289,6 +289,11 @@ def test_small_wave_kernels(kind, m, n, t, solver):
         assert out.rankA == ref.rankA and out.rankJ2 == ref.rankJ2 and out.code == ref.code
         assert np.array_equal(out.jpvtA, ref.jpvtA)
         assert rel(out.p, ref.p) <= (1e-5 if kind == "graded" else 1e-9)
+        if ref.code == 1:       # full-rank A: J2 is well defined, so are the leading pivots and |d| of the truncated factorisation
+            r = ref.rankJ2
+            assert np.array_equal(out.jpvtJ2[:r], ref.jpvtJ2[:r])
+            assert abs(np.linalg.norm(out.d) - np.linalg.norm(ref.d)) <= 1e-12 * np.linalg.norm(ref.d)
+            assert np.abs(np.abs(out.d[:r]) - np.abs(ref.d[:r])).max() <= 1e-6 * np.abs(ref.d).max()
 
 
 def test_pipelined_batch_on_caller_stream():
@@ -435,17 +440,42 @@ def test_nonfinite_and_degenerate_inputs_return(kind, m, n, t, solver):
     assert rel(solver.solve(J, rx, A, cx).p, ref.p) <= TOL_P
 
 
+def _plateau_problem(pid, m, n, t):
+    """J whose J2 = (J * F_A.Q)[:, t+1:] has a spectrum of three plateaus and an exactly rank-deficient rest, every plateau at
+    least 10x away from the pseudo_rank threshold |R11| sqrt(len) eps_rank of the eps_rank it is meant for (R11 lies between
+    0.3 and 1 for this spectrum): eps_rank = 1e-3 must count plateau 1 only, 1e-6 plateaus 1-2, 1e-12 plateaus 1-3."""
+    _, rx, A, cx = synth.make_problem(pid, m, n, t)
+    n2 = n - t
+    F_A = go.qr_colnorm(A.T)
+    Q1 = F_A.Q_mul(np.eye(n))
+    r1, r2, r3 = n2 // 3, n2 // 4, n2 // 5
+    L = np.sqrt(n2)
+    s = np.zeros(n2)
+    s[:r1] = np.linspace(1.0, 0.5, r1)
+    s[r1:r1 + r2] = L * np.linspace(2e-5, 1e-5, r2)
+    s[r1 + r2:r1 + r2 + r3] = L * np.linspace(2e-8, 1e-8, r3)
+    U, _ = np.linalg.qr(synth.normal_stream(pid, 6, m * n2).reshape((m, n2), order="F"))
+    V, _ = np.linalg.qr(synth.normal_stream(pid, 7, n2 * n2).reshape((n2, n2), order="F"))
+    J2 = (U * s) @ V.T
+    J1 = synth.normal_stream(pid, 8, m * t).reshape((m, t), order="F")
+    return np.hstack([J1, J2]) @ Q1.T, rx, A, cx, (r1, r1 + r2, r1 + r2 + r3)
+
+
 @pytest.mark.parametrize("m,n,t", [(300, 40, 5), (1200, 280, 30), (512, 64, 8), (700, 300, 100)])
-@pytest.mark.parametrize("eps_rank", [1e-3, 1e-6, 1e-12])
-def test_eps_rank_drives_the_ranks(eps_rank, m, n, t, solver):
-    """pseudo_rank (src/enlsip_functions.jl:17-31) with other thresholds on a graded spectrum: ranks and p follow the oracle."""
-    J, rx, A, cx = synth.make_graded_J(7100 + m + n, m, n, t)
-    ref = go.gn_subproblem(J, rx, A, cx, eps_rank)
-    out = solver.solve(J, rx, A, cx, eps_rank=eps_rank)
-    assert (out.rankA, out.code) == (ref.rankA, ref.code)
-    assert abs(out.rankJ2 - ref.rankJ2) <= 1          # a diagonal entry within rounding of the threshold may fall either side
-    if out.rankJ2 == ref.rankJ2:
-        assert rel(out.p, ref.p) <= 1e-4              # cond up to 1 / eps_rank
+def test_eps_rank_drives_the_ranks(m, n, t, solver):
+    """pseudo_rank (src/enlsip_functions.jl:17-31) under three thresholds on a spectrum with a >= 10x gap either side of every
+    threshold: the ranks are EXACTLY the oracle's (and the designed ones), and p follows the oracle."""
+    J, rx, A, cx, designed = _plateau_problem(7100 + m + n, m, n, t)
+    got = []
+    for eps_rank, want in zip((1e-3, 1e-6, 1e-12), designed):
+        ref = go.gn_subproblem(J, rx, A, cx, eps_rank)
+        out = solver.solve(J, rx, A, cx, eps_rank=eps_rank)
+        assert (out.rankA, out.code) == (ref.rankA, ref.code) == (t, 1)
+        assert out.rankJ2 == ref.rankJ2 == want, (eps_rank, out.rankJ2, ref.rankJ2, want)
+        assert np.array_equal(out.jpvtJ2[:want], ref.jpvtJ2[:want])
+        assert rel(out.p, ref.p) <= 1e-6              # cond up to 1e8 at the lowest threshold
+        got.append(out.rankJ2)
+    assert got[0] < got[1] < got[2] < n - t
 
 
 @pytest.mark.parametrize("m,n,t", [(600, 40, 6), (900, 300, 20), (700, 300, 100)])
