@@ -300,4 +300,50 @@ function gn_search_direction_batched_hip(h::Handle, Js::Array{Float64,3}, rxs::M
     return P, infos
 end
 
+# ---- one tall Jacobian, rows sharded over the GPUs of a node (config C4): the library's TSQR collective -------------------------
+#
+# One Julia process per GPU (Distributed / MPI.jl); every rank creates its Handle on its own device.  Rank 0 obtains the RCCL
+# unique id, the caller's own transport carries its 128 bytes to the other ranks (e.g. `MPI.Bcast!(id, 0, comm)` or
+# `remotecall_fetch`), then every rank calls `tsqr_init_rccl!` (collective: ncclCommInitRank inside the library) once.
+# Afterwards `gn_search_direction_tsqr_hip` is `gn_search_direction` for a Jacobian whose rows live on several GPUs: rank g
+# passes DEVICE pointers to its row block of J and rx (e.g. `pointer(::ROCArray)` from AMDGPU.jl) and the replicated C.A', cx;
+# every rank gets the same p, ||d||, ranks and pivots back.  The one exchange step is an ncclAllGather of the packed triangles
+# (8 n2 (n2 + 1) / 2 bytes per rank) over xGMI, issued by the library on the handle's stream.
+
+"""    tsqr_unique_id() -> Vector{UInt8} (128 bytes; call on rank 0, broadcast with your own transport)"""
+function tsqr_unique_id()
+    id = zeros(UInt8, 128)
+    rc = GC.@preserve id ccall((:enlsip_gn_tsqr_unique_id, LIB), Cint, (Ptr{UInt8},), id)
+    rc == 0 || error("enlsip_gn_tsqr_unique_id failed with code $rc (RCCL not loadable?)")
+    return id
+end
+
+"""    tsqr_init_rccl!(h, id, nranks, rank)  (collective over all ranks; rank is 0-based)"""
+function tsqr_init_rccl!(h::Handle, id::Vector{UInt8}, nranks::Integer, rank::Integer)
+    length(id) == 128 || error("the RCCL unique id has 128 bytes")
+    GC.@preserve id check(h, ccall((:enlsip_gn_tsqr_init_rccl, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint),
+                                   h.ptr, id, nranks, rank))
+end
+
+"""    gn_search_direction_tsqr_hip(h, dJ, ldj, drx, dAt, dcx, m_loc, n, t, ε_rank) -> (p, d_lead, d_norm, info, jpvtJ2)
+
+Collective.  `dJ`, `drx`: device pointers to this rank's `m_loc` rows of `J` (column-major, leading dimension `ldj`) and `rx`;
+`dAt`, `dcx`: device pointers to the replicated `C.A'` (`n×t`, column-major) and `C.cx` (C_NULL when `t == 0`).  Replaces
+`JQ1 = J * F_A.Q` … `qr(J2, ColumnNorm())` … `sub_search_direction` (src/enlsip_functions.jl:219-225, :116-153) for that Jacobian;
+`d_lead` = leading `n − rankA` entries of `F_J2.Q' d`, `d_norm` = `norm(d_gn)` over all ranks (what :1222-1231 and :2448 consume).
+"""
+function gn_search_direction_tsqr_hip(h::Handle, dJ::Ptr{Float64}, ldj::Integer, drx::Ptr{Float64}, dAt::Ptr{Float64},
+                                      dcx::Ptr{Float64}, m_loc::Integer, n::Integer, t::Integer, ε_rank::Float64)
+    p = zeros(Float64, n); dlead = zeros(Float64, n); jJ = zeros(Int64, n)
+    dn = Ref{Float64}(0.0)
+    info = Ref(Info(0, 0, 0, 0, 0, 0))
+    GC.@preserve p dlead jJ check(h, ccall((:enlsip_gn_solve_tsqr, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Float64,
+         Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Info}, Ptr{Int64}),
+        h.ptr, m_loc, n, t, dJ, ldj, drx, dAt, max(n, 1), dcx, ε_rank, p, dlead, dn, info, jJ))
+    (info[].status & 1) != 0 && throw(LinearAlgebra.SingularException(0))
+    n2 = n - Int(info[].rankA)
+    return p, dlead[1:n2], dn[], info[], jJ[1:n2]
+end
+
 end # module
