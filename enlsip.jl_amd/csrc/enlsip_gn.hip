@@ -24,6 +24,7 @@
 #include "gn_kernels_update_v4.hpp"
 #include "gn_kernels_misc.hpp"
 #include "gn_kernels_lagrange.hpp"
+#include "gn_kernels_newton.hpp"
 #include "gn_kernels_qrcp_dist.hpp"
 #include "gn_kernels_qrcp_block.hpp"
 #include "gn_kernels_qrcp_block_reg.hpp"
@@ -750,6 +751,7 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->in_stage.p) (void)hipFree(h->in_stage.p);
     if (h->out_stage.p) (void)hipFree(h->out_stage.p);
     if (h->lag.p) (void)hipFree(h->lag.p);
+    if (h->newton.p) (void)hipFree(h->newton.p);
     if (h->cws.p) (void)hipFree(h->cws.p);
     if (h->scratch.p) (void)hipFree(h->scratch.p);
     if (h->xbuf.p) (void)hipFree(h->xbuf.p);
@@ -1044,3 +1046,4 @@ int enlsip_gn_solve(enlsip_gn_handle h, int64_t m, int64_t n, int64_t t, const d
 #include "gn_accessors.inc"
 #include "gn_tsqr.inc"
 #include "gn_lagrange.inc"
+#include "gn_newton.inc"

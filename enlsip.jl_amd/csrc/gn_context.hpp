@@ -103,7 +103,7 @@ struct enlsip_gn_context {
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
     gn::ProbState* state = nullptr;
     // staging for the host-pointer API
-    gn::DevBuf in_stage, out_stage, scratch, lag;
+    gn::DevBuf in_stage, out_stage, scratch, lag, newton;
     gn::ProbState* h_state = nullptr;   // pinned
     size_t h_state_cap = 0;
     // device-pointer inputs of the last solve (needed by resolve / get_JQ1 paths)

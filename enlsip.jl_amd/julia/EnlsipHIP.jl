@@ -300,6 +300,21 @@ function gn_search_direction_batched_hip(h::Handle, Js::Array{Float64,3}, rxs::M
     return P, infos
 end
 
+"""    newton_search_direction_hip(h, Γ_mat) -> (p, error)
+
+`newton_search_direction` (src/enlsip_functions.jl:348-423) after its two Hessian sums: the caller runs `hessian_res!` /
+`hessian_cons!` (:391-394, callback-bound) and passes `Γ_mat = r_mat - c_mat`; the library does :398-421 on the resident
+`F_A`, `p1`, `J` of the last solve.  Full-rank working sets only (`t == rankA`); the rank-deficient branch stays in Julia.
+"""
+function newton_search_direction_hip(h::Handle, Γ_mat::Matrix{Float64})
+    n = size(Γ_mat, 1)
+    p = zeros(Float64, n)
+    bad = Ref{Int64}(0)
+    GC.@preserve Γ_mat p check(h, ccall((:enlsip_gn_newton_direction, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ref{Int64}), h.ptr, 0, Γ_mat, n, p, bad))
+    return p, bad[] != 0
+end
+
 # ---- one tall Jacobian, rows sharded over the GPUs of a node (config C4): the library's TSQR collective -------------------------
 #
 # One Julia process per GPU (Distributed / MPI.jl); every rank creates its Handle on its own device.  Rank 0 obtains the RCCL

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "enlsip_gn_first_lagrange": (C.c_int, [_h, _i64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                            C.POINTER(C.c_double)]),
     "enlsip_gn_second_lagrange": (C.c_int, [_h, _i64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "enlsip_gn_newton_direction": (C.c_int, [_h, _i64, C.c_void_p, _i64, C.c_void_p, _ip]),
     "enlsip_gn_tsqr_local_dev": (C.c_int, [_h, _i64, _i64, _i64, C.c_void_p, _i64, C.c_void_p, C.c_void_p, _i64,
                                            C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, _dp, _ip]),
     "enlsip_gn_tsqr_combine_dev": (C.c_int, [_h, _i64, _i64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,

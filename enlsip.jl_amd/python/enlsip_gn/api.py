@@ -252,6 +252,16 @@ class GNSolver:
         self._chk(self._lib.enlsip_gn_second_lagrange(self._h, prob, _fptr(p), _fptr(ds), eps_rank, _fptr(lam)))
         return lam
 
+    def newton_direction(self, Gamma: np.ndarray, prob: int = 0):
+        """newton_search_direction (src/enlsip_functions.jl:348-423) after its Hessian sums: Gamma = r_mat - c_mat (n x n).
+        Returns (p, error) as the reference does (error = True: W22 not positive definite, p = 0)."""
+        G = np.asfortranarray(Gamma, dtype=np.float64)
+        n = G.shape[0]
+        p = np.zeros(n)
+        bad = C.c_int64(0)
+        self._chk(self._lib.enlsip_gn_newton_direction(self._h, prob, _fptr(G), n, _fptr(p), C.byref(bad)))
+        return p, bool(bad.value)
+
     # ---- instrumentation ------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self._chk(self._lib.enlsip_gn_set_profiling(self._h, 1 if on else 0))

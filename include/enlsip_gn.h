@@ -18,6 +18,7 @@
  *                               first/second_lagrange_mult_estimate!, search_direction_analys,
  *                               choose_subspace_dimensions, determine_solving_dim consume
  *                                                     src/enlsip_functions.jl:461-537, 1118-1291
+ *   enlsip_gn_newton_direction  newton_search_direction after its Hessian sums    src/enlsip_functions.jl:348-423
  *   enlsip_gn_solve_tsqr        (new design, no reference counterpart) the same subproblem with the ROWS of one
  *                               tall J sharded over the GPUs of a node: `JQ1 = J * F_A.Q` ... `qr(J2, ColumnNorm())`
  *                               (src/enlsip_functions.jl:219-223) as a TSQR whose one exchange step is an RCCL
@@ -195,6 +196,16 @@ int enlsip_gn_first_lagrange(enlsip_gn_handle h, int64_t prob, const double* gra
                              double eps_rank, double* lambda, double* grad_res);
 int enlsip_gn_second_lagrange(enlsip_gn_handle h, int64_t prob, const double* p_gn, const double* diag_scale,
                               double eps_rank, double* lambda);
+
+/* ---- Newton direction on the resident data of the last solve -------------------------------------------------
+ * newton_search_direction (src/enlsip_functions.jl:348-423) after its two Hessian sums (:391-396), which are callback-bound and
+ * stay with the caller: Gamma = r_mat - c_mat (n x n, host, column-major, ldg >= n).  Computes E = F_A.Q' Gamma F_A.Q (:398),
+ * W22 = E22 + J2'J2, W21 = E21 + J2'J1 (:405-409), d = -W21 p1 - J2' rx (:411), cholesky((W22 + W22')/2) and the two triangular
+ * solves (:414-420), p = F_A.Q [p1; p2] (:421) on the resident F_A, p1, J (J * F_A.Q is recomputed, as at :384).
+ * *not_posdef = 1 (and p = 0) when the symmetrised W22 is not positive definite (:417-420: `error = true`).  With rankA == n the
+ * reference returns p1 as it is (:374-376); so does this.  Returns -7 for a rank-deficient working set (t > rankA), whose
+ * E[F_L11.p, F_L11.p] branch (:400-403) is left to the host. */
+int enlsip_gn_newton_direction(enlsip_gn_handle h, int64_t prob, const double* Gamma, int64_t ldg, double* p, int64_t* not_posdef);
 
 /* ---- row-sharded TSQR building blocks (multi-GPU config C4) ----------
  * One tall residual Jacobian whose ROWS are sharded over G GPUs; the (small) constraint data

@@ -57,6 +57,11 @@ class HipBackend:
         m, n = J.shape
         return self.solver.JQ1(m, n)
 
+    def newton_direction(self, Gam):
+        # newton_search_direction after its Hessian sums (src/enlsip_functions.jl:398-421) on the resident factors
+        self.newton_calls = getattr(self, "newton_calls", 0) + 1
+        return self.solver.newton_direction(Gam)
+
     def sub_search_direction(self, J1, rx, cx, F_A, F_L11, F_J2, n, t, rankA, dimA, dimJ2, code):
         m = len(rx)
         return self.solver.resolve(m, n, t, dimA, dimJ2, code)

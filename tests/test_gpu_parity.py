@@ -493,6 +493,57 @@ def test_solve_with_dimension_overrides(m, n, t, solver):
         assert rel(out.p, p_ref) <= 1e-10             # (code 1 ignores dimA in both: full triangular solve, :131-133)
 
 
+def _newton_reference(J, rx, A, cx, Gam):
+    """The lines of newton_search_direction after its Hessian sums (src/enlsip_functions.jl:398-421) on the oracle's factors."""
+    m, n = J.shape
+    t = A.shape[0]
+    ref = go.gn_subproblem(J, rx, A, cx)
+    assert ref.rankA == t
+    Q1 = ref.F_A.Q_mul(np.eye(n))
+    b = -cx[ref.F_A.p - 1]
+    p1 = np.linalg.solve(np.triu(ref.F_A.R)[:t, :t].T, b) if t else np.zeros(0)
+    if t == n:
+        return p1, False            # :374-376: with rankA == n the reference returns p1 as it is (no F_A.Q applied)
+    JQ1 = J @ Q1
+    J1, J2 = JQ1[:, :t], JQ1[:, t:]
+    E = Q1.T @ Gam @ Q1
+    W22 = E[t:, t:] + J2.T @ J2
+    W21 = E[t:, :t] + J2.T @ J1
+    d = -W21 @ p1 - J2.T @ rx
+    sW = (W22 + W22.T) * 0.5
+    try:
+        L = np.linalg.cholesky(sW)
+    except np.linalg.LinAlgError:
+        return np.zeros(n), True
+    p2 = np.linalg.solve(L.T, np.linalg.solve(L, d))
+    return Q1 @ np.concatenate([p1, p2]), False
+
+
+@pytest.mark.parametrize("m,n,t", [(60, 12, 3), (300, 40, 0), (500, 130, 20), (54, 20, 13), (40, 9, 9)])
+def test_newton_direction_on_device(m, n, t, solver):
+    """enlsip_gn_newton_direction (src/enlsip_functions.jl:348-423 after the Hessian sums) against the same lines in NumPy on the
+    oracle's factors: a positive definite case, an indefinite one (error = true, p = 0), and after a truncated re-solve."""
+    J, rx, A, cx = synth.make_problem(8800 + m + n + t, m, n, t)
+    rng = np.random.default_rng(m + n)
+    S = rng.standard_normal((n, n))
+    Gam = 0.3 * (S + S.T) + 0.1 * rng.standard_normal((n, n))          # not exactly symmetric, as r_mat - c_mat need not be
+    solver.solve(J, rx, A, cx)
+    p, err = solver.newton_direction(Gam)
+    pr, errr = _newton_reference(J, rx, A, cx, Gam)
+    assert err == errr
+    assert rel(p, pr) <= 1e-10 if not errr else not p.any()
+    if n - t > 0:
+        bad = Gam - 1e4 * np.eye(n)                                      # W22 indefinite
+        p, err = solver.newton_direction(bad)
+        assert err and not p.any() and _newton_reference(J, rx, A, cx, bad)[1]
+        if t > 1:                                                        # a truncated re-solve must not leak its p1 into the Newton step
+            solver.resolve(m, n, t, t - 1, max(n - t - 1, 0), code=-1)
+            p, err = solver.newton_direction(Gam)
+            assert err == errr and (errr or rel(p, pr) <= 1e-10)
+    # the resident factors are still those of the solve
+    assert np.array_equal(solver.factor(0).p, go.gn_subproblem(J, rx, A, cx).jpvtA)
+
+
 def test_argument_errors(solver):
     from enlsip_gn import GNError
     J, rx, A, cx = synth.make_problem(1, 50, 10, 2)

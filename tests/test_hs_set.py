@@ -47,9 +47,12 @@ def test_hs_hip_backend_iteration_for_iteration(name):
     from hip_backend import HipBackend
     ref = _oracle_run(name)
     s = GNSolver(device=0)
-    res = hp.run(name, HipBackend(s))
+    backend = HipBackend(s)
+    res = hp.run(name, backend)
     s.close()
     assert res.iterations == ref.iterations
+    if any(b["code"] == 2 for b in ref.trace):      # Newton iterations ran: their direction came from enlsip_gn_newton_direction
+        assert getattr(backend, "newton_calls", 0) >= 1
     xs = max(1.0, float(np.abs(ref.x).max()))
     newton = False
     last_noise = False
