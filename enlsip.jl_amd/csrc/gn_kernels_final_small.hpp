@@ -139,6 +139,149 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : (
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same stage with TWO problems per wave (gn_wave_qrcp.hpp, second part): at most 32 rows of R0 and n2 + 1 <= 32 columns each —
+// the C5 shape (kp = 28, 29 columns), where the one-problem form leaves 35 lanes of every wave idle.  Lanes 0..31 / 32..63 carry
+// the columns of problem 2 b / 2 b + 1 of the launch; after the factorisation the wave finishes the two problems one after the
+// other with all of its lanes as workers (back substitution, p = F_A.Q [p1; p2], output records), exactly as k_pivot_small does.
+// LDS (doubles): tmp[kpm * 65] vbuf[128] dg[128] lpos[64 ints] pbuf[nv]
+// ---------------------------------------------------------------------------------------------------------------------------------
+inline size_t final_small2_lds_bytes(int kpm, int nv) { return (size_t)(kpm * 65 + 128 + 128 + 32 + nv + 8) * 8; }
+
+__global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) {      // 3 waves per SIMD: 168 registers
+    constexpr int NR = 32;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int kpm = a.matd;                            // rows of the finished-row image (launch-wide bound on kp, <= 32)
+    double* tmp = smem;
+    double* vbuf = tmp + kpm * 65;
+    double* dg = vbuf + 128;
+    int* lpos = reinterpret_cast<int*>(dg + 128);
+    double* pbuf = dg + 128 + 32;
+    const int ln = threadIdx.x, lh = ln & 31, hb = ln & 32, half = ln >> 5;
+    const int pidx = 2 * blockIdx.x + half;            // the lane's problem inside the launch
+    const bool have = pidx < nprob;
+    const int prob_l = a.prob0 + (have ? pidx : 0);
+    const int n = a.n, m = a.m, t = a.t, kA = a.kA, ldr = a.ldr, ldw = a.ldw;
+    int rankA = 0, n2 = 0, kp = 0;
+    bool ok = false;
+    if (have) {
+        const ProbState st = a.state[prob_l];
+        rankA = st.rankA; n2 = st.n2; kp = st.kp;
+        // a problem whose J2 is wider than the launch shape (rank-deficient A) is redone by the caller with the true width
+        ok = kp <= NR && kp <= kpm && n2 + 1 <= 32 && !(a.n2cap > 0 && n2 > a.n2cap);
+        if (!ok) kp = 0;
+    }
+    const double* W = a.W + (size_t)prob_l * a.sW;
+    double* Rt = a.Rt + (size_t)prob_l * a.sRt;
+    // ---- R0 (upper trapezoid) and z: lane = row for the loads, columns through the LDS image ------------------------------
+    for (int c0 = 0; c0 < 32; c0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            v[u] = 0.0;
+            if (ok && lh < kp) {
+                if (c < n2) v[u] = (lh <= c) ? W[lh + (size_t)(rankA + c) * ldw] : 0.0;
+                else if (c == n2) v[u] = W[lh + (size_t)n * ldw];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (lh < kpm) tmp[lh * 65 + hb + c0 + u] = v[u];
+    }
+    if (a.zsave && ok && lh < kp) a.zsave[(size_t)prob_l * a.sZ + lh] = W[lh + (size_t)n * ldw];
+    wave_mem_sync();
+    double x[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) x[r] = (r < kp && lh <= n2) ? tmp[r * 65 + ln] : 0.0;
+    wave_mem_sync();                                   // every lane has taken its column before the image receives finished rows
+    WaveQrcp2 q{};
+    q.rows = kp; q.k = kp; q.ncand = ok ? n2 : 0; q.npart = ok ? n2 + 1 : 0;
+    q.tmp = tmp; q.vbuf = vbuf; q.dg = dg; q.F = Rt; q.ldf = ldr; q.tau = a.tauJ + (size_t)prob_l * a.sTauJ;
+    const int k0 = __builtin_amdgcn_readlane(kp, 0), k1 = __builtin_amdgcn_readlane(kp, 32);
+    const int kmax = k0 > k1 ? k0 : k1;
+    int mypos = lh;
+    if (kmax > 0) wave_qrcp2<NR>(x, q, kmax, ln, mypos);
+    wave_mem_sync();
+
+    // ---- the wave finishes problem 0, then problem 1 -----------------------------------------------------------------------------
+    for (int hsel = 0; hsel < 2; ++hsel) {
+        const int hbu = 32 * hsel;
+        if (2 * blockIdx.x + hsel >= nprob) continue;
+        if (!__builtin_amdgcn_readlane((int)ok, hbu)) continue;
+        const int prob = a.prob0 + 2 * blockIdx.x + hsel;
+        const int n2u = __builtin_amdgcn_readlane(n2, hbu), kpu = __builtin_amdgcn_readlane(kp, hbu), rAu = __builtin_amdgcn_readlane(rankA, hbu);
+        const int myposh = __shfl(mypos, hbu + lh);     // the half's positions in lanes 0..31
+        ProbState* stp = a.state + prob;
+        double* Rtu = a.Rt + (size_t)prob * a.sRt;
+        long long* jpvtJ = a.jpvtJ + (size_t)prob * a.sJJ;
+        const double* FA = a.FA + (size_t)prob * a.sFA;
+        const double* tauA = a.tauA + (size_t)prob * a.sTauA;
+        const double* p1 = a.p1 + (size_t)prob * a.sP1;
+        const double* bvec = a.bvec + (size_t)prob * a.sB;
+        const double* Wu = a.W + (size_t)prob * a.sW;
+        const double* dgh = dg + 2 * hbu;
+        const bool inh = ln < 32;
+        int status = 0;
+        if (inh && ln < n2u) jpvtJ[myposh] = ln + 1;
+        wave_mem_sync();
+        if (inh && ln <= n2u) lpos[myposh] = ln;
+        wave_mem_sync();
+        const int lp = (inh && ln <= n2u) ? lpos[ln] : 0;       // lane i: the column that sits at position i
+        for (int P = 0; P <= n2u; ++P) {                          // upper parts of the factor columns (and the carried one)
+            const int src = lpos[P];
+            if (ln < kpu && ln <= P) Rtu[ln + (size_t)P * ldr] = tmp[ln * 65 + hbu + src];
+        }
+        int rankJ2 = 0;
+        if (kpu > 0) {
+            const double d0 = fabs(dgh[0]);
+            if (!(d0 < a.eps_rank)) {
+                const double tol = d0 * sqrt((double)kpu) * a.eps_rank;
+                const bool fail = (ln < kpu) && !(fabs(dgh[ln < kpu ? ln : 0]) > tol);
+                const unsigned long long mk = __ballot(fail);
+                rankJ2 = mk ? (int)__builtin_ctzll(mk) : kpu;
+            }
+        }
+        int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
+        dimJ2 = dimJ2 < kpu ? dimJ2 : kpu;
+        // dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]: lane r carries row r of the right-hand side
+        double zw = (ln < dimJ2) ? tmp[ln * 65 + hbu + n2u] : 0.0;
+        for (int i = dimJ2 - 1; i >= 0; --i) {
+            const int li = lpos[i];
+            const double dkk = tmp[i * 65 + hbu + li];
+            if (dkk == 0.0) status |= 1;
+            const double yi = wave_bcast(zw, i) / dkk;
+            if (ln == i) zw = yi;
+            if (ln < i) zw -= tmp[ln * 65 + hbu + li] * yi;
+        }
+        // y = [p1 ; p2],  p2[pJ[i]-1] = (i < dimJ2 ? dp2[i] : 0)
+        for (int i = ln; i < rAu; i += WAVE) pbuf[i] = p1[i];
+        if (inh && ln < n2u) pbuf[rAu + lp] = (ln < dimJ2) ? zw : 0.0;
+        wave_mem_sync();
+        wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);      // p = F_A.Q * y
+        wave_mem_sync();
+        if (a.p_out)
+            for (int i = ln; i < n; i += WAVE) a.p_out[(size_t)prob * a.sPo + i] = pbuf[i];
+        if (a.b_out)
+            for (int i = ln; i < t; i += WAVE) a.b_out[(size_t)prob * a.sBo + i] = bvec[i];
+        if (a.d_out)
+            for (int i = ln; i < m; i += WAVE)
+                a.d_out[(size_t)prob * a.sDo + i] = (i < kpu) ? tmp[i * 65 + hbu + n2u] : Wu[i + (size_t)n * ldw];
+        if (a.jA_out)
+            for (int i = ln; i < t; i += WAVE) a.jA_out[(size_t)prob * a.sJAo + i] = a.jpvtA[(size_t)prob * a.sJA + i];
+        if (a.jL_out)
+            for (int i = ln; i < kA; i += WAVE) a.jL_out[(size_t)prob * a.sJLo + i] = a.jpvtL[(size_t)prob * a.sJL + i];
+        if (a.jJ_out && inh && ln < n2u) a.jJ_out[(size_t)prob * a.sJJo + myposh] = ln + 1;
+        if (ln == 0) {
+            stp->rankJ2 = rankJ2;
+            stp->dimJ2 = dimJ2;
+            stp->status |= status;
+        }
+        wave_mem_sync();                               // lpos / pbuf are reused by the second problem
+    }
+}
+
 // Returns false when the launch shape is outside the kernel's range (the caller uses k_pivot_solve).
 inline bool launch_pivot_small(int kp_launch, int n2_launch, int batch, hipStream_t s, FinalArgs a) {
     if (kp_launch > 64 || n2_launch + 1 > 64 || a.refactor != 1 || a.dsrc) return false;
@@ -146,6 +289,11 @@ inline bool launch_pivot_small(int kp_launch, int n2_launch, int batch, hipStrea
     a.nv = (int)((mx + 7) / 8 * 8);
     a.matd = (kp_launch > 0 ? kp_launch : 1) * 65 + 1;
     a.matd = (a.matd + 1) / 2 * 2;
+    if (kp_launch <= 32 && n2_launch + 1 <= 32 && batch > 1) {      // two problems per wave
+        a.matd = kp_launch > 0 ? kp_launch : 1;
+        hipLaunchKernelGGL(k_pivot_small2, dim3((batch + 1) / 2), dim3(64), final_small2_lds_bytes(a.matd, a.nv), s, a, batch);
+        return true;
+    }
     const size_t lds = final_small_lds_bytes(0, a.nv) + (size_t)a.matd * 8;
     if (kp_launch <= 32) hipLaunchKernelGGL(k_pivot_small<32>, dim3(batch), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(k_pivot_small<64>, dim3(batch), dim3(64), lds, s, a);

@@ -182,4 +182,152 @@ __device__ __forceinline__ int wave_pseudo_rank(const double* dg, const int len,
     return mk ? (int)__builtin_ctzll(mk) : len;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// TWO problems per wave: lanes 0..31 carry the columns of one problem, lanes 32..63 those of another (at most 32 columns
+// including carried right-hand sides, at most NR <= 32 rows each).  With n2 + 1 = 29 columns (C5) a one-problem wave leaves
+// 35 of its 64 lanes idle; the pivot stage is latency bound, so halving the number of waves nearly halves its time.
+// Everything wave-uniform in the one-problem form (pivot lane, reflector scalars, row counts) becomes uniform per HALF.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ ArgMax half_argmax(double val, int pos, int idx, int ln) {
+    ArgMax a = {val, pos, idx};
+    am_step<0xB1>(a);
+    am_step<0x4E>(a);
+    am_step<0x141>(a);
+    am_step<0x140>(a);
+    ArgMax r[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        r[h] = {readlane_f64(a.val, 32 * h), __builtin_amdgcn_readlane(a.pos, 32 * h), __builtin_amdgcn_readlane(a.idx, 32 * h)};
+        const double ov = readlane_f64(a.val, 32 * h + 16);
+        const int op = __builtin_amdgcn_readlane(a.pos, 32 * h + 16);
+        const int oi = __builtin_amdgcn_readlane(a.idx, 32 * h + 16);
+        if (am_better(ov, op, r[h].val, r[h].pos)) r[h] = {ov, op, oi};
+    }
+    return (ln & 32) ? r[1] : r[0];
+}
+// x of lane srcA (lower half) / srcB (upper half), both wave-uniform, in every lane of the respective half
+__device__ __forceinline__ double half_bcast(double x, int srcA, int srcB, int ln) {
+    const double a = readlane_f64(x, srcA), b = readlane_f64(x, srcB);
+    return (ln & 32) ? b : a;
+}
+
+struct WaveQrcp2 {        // per-lane values are those of the lane's half
+    int rows, k;          // rows / steps of the lane's problem
+    int ncand, npart;     // columns (pivot candidates) / columns + carried right-hand sides, counted inside the half
+    double* tmp;          // LDS: finished rows of both problems, tmp[row * 65 + lane]
+    double* vbuf;         // LDS: 2 x 64
+    double* dg;           // LDS: 2 x 64
+    double* F;            // the lane's problem: factor matrix (receives v below the diagonal), leading dimension ldf
+    long long ldf;
+    double* tau;          // the lane's problem
+};
+
+template <int NR, int S>
+__device__ __forceinline__ void wave_qrcp2_substep(double (&x)[NR], const WaveQrcp2& q, const int j, const int ln, int& mypos,
+                                                   double& vn1, double& vn2) {
+    const double tol3z = 1.4901161193847656e-08;  // sqrt(eps), dlaqp2
+    const int lh = ln & 31, hb = ln & 32;
+    const bool act = j < q.k;
+    const bool cand = act && (lh < q.ncand) && (mypos >= j);
+    const ArgMax am = half_argmax(cand ? pivot_key(vn1) : -1.0, mypos, ln, ln);
+    const int pl = am.idx, pp = am.pos;
+    const int plA = __builtin_amdgcn_readlane(pl, 0), plB = __builtin_amdgcn_readlane(pl, 32);
+    if (act) {
+        if (mypos == j) mypos = pp;
+        if (ln == pl) mypos = j;
+    }
+    double* vb = q.vbuf + 2 * hb;                  // [half][64]
+    if (act && ln == pl) {
+#pragma unroll
+        for (int r = S + 1; r < NR; ++r) vb[r] = x[r];
+    }
+    wave_mem_sync();
+    double v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = (r > S) ? vb[r] : 0.0;
+    double dotraw = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < NR / 8; ++ch) {
+        if (8 * ch + 7 > S) {
+            double pc = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = 8 * ch + rr;
+                if (r > S) pc += x[r] * v[r];
+            }
+            dotraw += pc;
+        }
+    }
+    const Reflector h = make_reflector(half_bcast(x[S], plA, plB, ln), half_bcast(dotraw, plA, plB, ln));    // uniform per half
+    const double tau = h.tau, scale = h.scale;
+    const bool upd = act && (mypos > j) && (lh < q.npart);
+    const double dot = x[S] + scale * dotraw;          // v' x
+    if (act && ln == pl) x[S] = h.beta;
+    if (upd && tau != 0.0) {
+        const double wd = tau * dot;
+        const double ws = wd * scale;
+        x[S] -= wd;
+#pragma unroll
+        for (int r = S + 1; r < NR; ++r) x[r] -= ws * v[r];
+    }
+    // row j is final in every column at a position >= j; the Householder vector goes to column j of the half's F
+    if (act && mypos >= j && lh < q.npart) q.tmp[j * 65 + ln] = x[S];
+    if (act && lh == 0) {
+        q.tau[j] = tau;
+        q.dg[2 * hb + j] = h.beta;
+    }
+    if (act && j + 1 + lh < q.rows && S + 1 + lh < NR) q.F[(size_t)j * q.ldf + j + 1 + lh] = vb[S + 1 + lh] * scale;
+    wave_mem_sync();          // every reader of vb is done before the next publish
+    if (upd && lh < q.ncand && vn1 != 0.0) {
+        const double ajc = x[S];
+        double temp = 1.0 - (fabs(ajc) / vn1) * (fabs(ajc) / vn1);
+        temp = temp > 0.0 ? temp : 0.0;
+        const double qq = vn1 / vn2;
+        const double temp2 = temp * qq * qq;
+        if (temp2 <= tol3z) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int r = S + 1; r < NR; ++r) s2 += x[r] * x[r];
+            const double nv = (j + 1 < q.rows) ? sqrt(s2) : 0.0;
+            vn1 = nv;
+            vn2 = nv;
+        } else {
+            vn1 *= sqrt(temp);
+        }
+    }
+}
+
+// Driver of the two-problem form; kmax = the larger step count of the two problems (wave-uniform).  Returns the row offset of the
+// registers (as wave_qrcp).
+template <int NR>
+__device__ __forceinline__ int wave_qrcp2(double (&x)[NR], const WaveQrcp2& q, const int kmax, const int ln, int& mypos) {
+    double vn1;
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < NR / 8; ++ch) {
+            double pc = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) pc += x[8 * ch + rr] * x[8 * ch + rr];
+            s += pc;
+        }
+        vn1 = sqrt(s);
+    }
+    double vn2 = vn1;
+    mypos = ln & 31;
+    int j0 = 0;
+    for (;;) {
+#define GN_WQ2_STEP(S) \
+    if (j0 + S < kmax) wave_qrcp2_substep<NR, S>(x, q, j0 + S, ln, mypos, vn1, vn2);
+        GN_WQ2_STEP(0) GN_WQ2_STEP(1) GN_WQ2_STEP(2) GN_WQ2_STEP(3)
+#undef GN_WQ2_STEP
+        if (j0 + WQ_UNROLL >= kmax) break;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] = (r + WQ_UNROLL < NR) ? x[(r + WQ_UNROLL < NR) ? r + WQ_UNROLL : r] : 0.0;
+        j0 += WQ_UNROLL;
+    }
+    return j0;
+}
+
 }  // namespace gn
