@@ -19,6 +19,29 @@ int main(void) {
     if (rc != 0) {
         const char* msg = enlsip_gn_last_error(NULL);
         printf("create refused (rc %d): %s\n", rc, msg ? msg : "(no message)");
+        /* every entry point must turn a NULL handle into an error code, never into an access */
+        {
+            double x[4] = {0, 0, 0, 0};
+            int64_t i4[4] = {0, 0, 0, 0}, r = 0, c = 0;
+            enlsip_gn_info inf;
+            int bad = 0;
+            bad += enlsip_gn_solve(NULL, 2, 2, 0, x, 2, x, NULL, 2, NULL, 1e-8, -1, -1, x, NULL, x, &inf, NULL, NULL, i4) == 0;
+            bad += enlsip_gn_solve_batched(NULL, 1, 2, 2, 0, x, 2, 4, x, NULL, 2, 0, NULL, 1e-8, x, NULL, x, &inf, NULL, NULL, i4) == 0;
+            bad += enlsip_gn_solve_batched_dev(NULL, 1, 2, 2, 0, x, 2, 4, x, NULL, 2, 0, NULL, 1e-8, x, NULL, x, NULL, NULL, NULL, i4) == 0;
+            bad += enlsip_gn_factor_constraints(NULL, 2, 2, 0, NULL, 2, NULL, 1e-8, &inf) == 0;
+            bad += enlsip_gn_factor_shape(NULL, 0, 0, &r, &c) == 0;
+            bad += enlsip_gn_get_R(NULL, 0, 0, x, 2) == 0;
+            bad += enlsip_gn_apply_qt(NULL, 0, 0, x) == 0;
+            bad += enlsip_gn_resolve(NULL, 0, 0, 0, 1, x, x, x) == 0;
+            bad += enlsip_gn_gradient(NULL, 0, x) == 0;
+            bad += enlsip_gn_newton_direction(NULL, 0, x, 2, x, &r) == 0;
+            bad += enlsip_gn_tsqr_set_exchange(NULL, NULL, NULL, 1, 0) == 0;
+            bad += enlsip_gn_solve_tsqr(NULL, 2, 2, 0, x, 2, x, NULL, 2, NULL, 1e-8, x, x, x, &inf, i4) == 0;
+            bad += enlsip_gn_synchronize(NULL) == 0;
+            bad += enlsip_gn_set_profiling(NULL, 1) == 0;
+            bad += enlsip_gn_destroy(NULL) != 0;            /* destroying nothing is fine */
+            if (bad) { printf("%d entry points accepted a NULL handle\n", bad); return 8; }
+        }
         return (msg && msg[0]) ? 3 : 4;
     }
     double J[M * N], rx[M], At[N * T], cx[T];
