@@ -312,7 +312,11 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
                     e1 = h->upd_ev[h->upd_used++];
                     GN_HIP(hipEventRecord(e0, h->stream));
                 }
-                if (use_mfma) launch_update_v4(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
+                if (use_mfma && lvl0) {
+                    // the J2 columns in 32-column blocks, the carried right-hand side (always the 32 j + 1-th column) on its own
+                    a.skip_rhs = 1;
+                    launch_update_v4(h->plan.RPL, a, L.groups, ntrail - 1, (int)P.batch, h->stream);
+                } else if (use_mfma) launch_update_v4(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
                 else launch_update_refl(h, a, L.groups, ntrail);
                 if (e1) {
                     GN_HIP(hipEventRecord(e1, h->stream));

@@ -39,6 +39,7 @@ struct CaqrArgs {
     double* C;          long long sC;
     int reverse;        // 1: apply reflectors in reverse order (Q instead of Q')
     int prob0;          // problem index offset (accessors address one problem of a batch)
+    int skip_rhs;       // level-0 MFMA update: 1 = the carried right-hand side (the last trailing column) is left to k_caqr_update_rhs
     int npass;          // factor kernel: 1 = the column right after a panel narrower than 32 (the carried right-hand side
                         // d, when it is the ONLY trailing column) rides through the factorisation as a passenger: it receives
                         // every reflector but is never factored, and no trailing-update launch is needed for the panel

@@ -335,6 +335,92 @@ __device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, doub
     else v4_body<RPL, TRI, CFULL, 0, NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The carried right-hand side d = Q'(-J1 p1 - rx) is the LAST trailing column of every panel, so the trailing column count is
+// always 32 j + 1: in the block kernel above that one column cost a whole 16-column block per tile and panel — 13 % of the
+// level-0 workgroups of a C2 solve, each reading 15 spare columns from HBM for nothing.  This kernel applies the tile's block
+// reflector to that single column instead: d -= V (T' (V' d)) with the tile's V read ONCE (row pairs, 16-byte full-line loads,
+// kept in registers), the 32 dot products reduced with the batched wave reductions, T' applied by one wave.
+// Runs as the LAST block index (blockIdx.y) of the block kernel's own grid, so that the tile's V is read while the column blocks of
+// the same tile keep it hot in the XCD's L2 (as a launch of its own, after the block kernel, it re-read 400 MB of reflectors per
+// panel from HBM and gave the gain back).  256 threads: thread = row pair of a 512-row tile (RPL = 8); RPL = 4 uses 128 of them.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int RPL>
+__device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB], double* w2s) {
+    constexpr int NWV = 4;                                               // waves of the block kernel's workgroup
+    const int prob = blockIdx.z + a.prob0;
+    const ProbState st = a.state[prob];
+    const int r0 = a.panel * PB;
+    if (r0 >= st.kp) return;
+    const int bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
+    if (st.n2 + 1 - (r0 + bw) < 1) return;
+    const int col0 = st.rankA + r0;
+    const int g = blockIdx.x;
+    const double* Wm = a.W + prob * a.sW;
+    double* dcol = a.W + prob * a.sW + (size_t)a.n * a.ldw;
+    const double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
+    const long long tile_row0 = (long long)r0 + (long long)g * a.F * 32;
+    const long long blocks_here = (long long)a.nblocks - (long long)g * a.F;
+    const int nvu = (int)(blocks_here < a.F ? blocks_here : a.F);        // valid 32-row units of this tile
+    const int tid = threadIdx.x, ln = lane_id(), w = wave_id();
+    const int s0 = 2 * tid;                                              // first slot of the thread's row pair
+    const bool live = (s0 < 64 * RPL) && (s0 >> 5) < nvu;
+    // V row pairs (structure of the tile's first 32 rows: unit lower trapezoid; columns >= bw do not exist), d row pair
+    v4_d2 v[PB];
+    v4_d2 dd = (v4_d2){0.0, 0.0};
+    const double* vrow = Wm + (size_t)col0 * a.ldw + tile_row0 + s0;
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j) v[j] = *(const v4_d2*)(vrow + (size_t)j * a.ldw);
+        dd = *(const v4_d2*)(dcol + tile_row0 + s0);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int s = s0 + p;
+            double x = live ? v[j][p] : 0.0;
+            if (s0 < PB) x = (s > j) ? x : ((s == j) ? 1.0 : 0.0);
+            v[j][p] = (j < bw && live) ? x : 0.0;
+        }
+    }
+    // w1 = V' d: per-thread partial products, batched wave reductions, partials of the waves through LDS
+#pragma unroll
+    for (int j8 = 0; j8 < PB; j8 += 8) {
+        double pr[8], rs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pr[u] = v[j8 + u][0] * dd[0] + v[j8 + u][1] * dd[1];
+        wave_allsum8(pr, rs);
+        if (ln == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[w][j8 + u] = rs[u];
+        }
+    }
+    __syncthreads();
+    // w2 = -T' w1 (T upper triangular, column-major): lane k of wave 0
+    if (w == 0 && ln < PB) {
+        double acc = 0.0;
+        for (int l = 0; l <= ln; ++l) {
+            double w1 = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NWV; ++ww) w1 += part[ww][l];
+            acc += T[l + ln * PB] * w1;
+        }
+        w2s[ln] = (ln < bw) ? -acc : 0.0;
+    }
+    __syncthreads();
+    if (live) {
+        double d0 = dd[0], d1 = dd[1];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) {
+            const double wk = w2s[k];
+            d0 += v[k][0] * wk;
+            d1 += v[k][1] * wk;
+        }
+        *(v4_d2*)(dcol + tile_row0 + s0) = (v4_d2){d0, d1};
+    }
+}
+
 #ifndef ENLSIP_V4_CW
 #define ENLSIP_V4_CW 32          // columns per workgroup (experiment: 16 with 3 workgroups per CU)
 #endif
@@ -344,6 +430,10 @@ __global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update
     __shared__ __attribute__((aligned(16))) double W2l[PB * PB];         // W2 = -T' W1   [k][j]
 
     V4_STAMP(6);
+    if (!TRI && a.skip_rhs && blockIdx.y == gridDim.y - 1) {             // the carried right-hand side of this tile
+        v4_rhs_body<RPL>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l);
+        return;
+    }
     const int prob = blockIdx.z + a.prob0;
     const ProbState st = a.state[prob];
     const int r0 = a.panel * PB;
@@ -353,7 +443,7 @@ __global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update
     c.col0 = st.rankA + r0;
     const int g = blockIdx.x;
     const int first = r0 + c.bw;
-    const int ncols = st.n2 + 1 - first;
+    const int ncols = st.n2 + 1 - first - ((!TRI && a.skip_rhs) ? 1 : 0);
     c.cb0 = blockIdx.y * ENLSIP_V4_CW;
     if (c.cb0 >= ncols) return;
     c.rows_valid = 0;
@@ -386,7 +476,8 @@ __global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update
 }
 
 inline void launch_update_v4(int RPL, const CaqrArgs& a, int groups, int ncols, int batch, hipStream_t s) {
-    dim3 grid(groups, (ncols + ENLSIP_V4_CW - 1) / ENLSIP_V4_CW, batch);
+    // level 0 with skip_rhs: ncols counts the J2 columns only; one more block index carries the right-hand side
+    dim3 grid(groups, (ncols + ENLSIP_V4_CW - 1) / ENLSIP_V4_CW + ((a.level == 0 && a.skip_rhs) ? 1 : 0), batch);
     if (a.level == 0) {
         if (RPL == 8) hipLaunchKernelGGL((k_caqr_update_v4<8, false>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_caqr_update_v4<4, false>), grid, dim3(256), 0, s, a);
