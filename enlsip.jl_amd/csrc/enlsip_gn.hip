@@ -543,6 +543,8 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
     h->chunk0 = 0;  // ... and to the resident chunk by solve_chunked
     const bool reuse = h->reuse_once;
     h->reuse_once = false;
+    const bool upper_in = h->upper_once && t == 0 && m <= n;      // J is upper triangular (and unconstrained): it IS its own R0, Q0 = I
+    h->upper_once = false;
     int rc = check_limits(h, batch, m, n, t);
     if (rc) return rc;
     if (ldj < m) { h->err = "ldj < m"; return -7; }
@@ -596,8 +598,10 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         mark(2);
         GN_TRACE(h, "attempt %d n2_launch=%d: J*Q1 done", attempt, n2_launch);
         // 3. CAQR of [J2 | d]
-        rc = run_caqr(h, n2_launch);
-        if (rc) return rc;
+        if (!upper_in) {
+            rc = run_caqr(h, n2_launch);
+            if (rc) return rc;
+        }
         mark(3);
         GN_TRACE(h, "CAQR done");
         // 4. pivoted QR of R0 + solves + outputs

@@ -60,6 +60,7 @@ struct enlsip_gn_context {
         const double* qb = nullptr; long long sQb = 0;
         bool valid = false;
     } cdist;
+    bool upper_once = false;         // the next solve_dev gets an upper-triangular J (one gathered triangle of the TSQR combine stage): no CAQR needed
     bool reuse_once = false;         // the next solve_dev skips the constraint stage (enlsip_gn_solve_factored)
     bool trace = false;              // ENLSIP_GN_TRACE=1: stage names on stderr with a stream synchronisation after each (fault hunting)
     bool constraints_only = false;   // resident: F_A, F_L11 only (enlsip_gn_factor_constraints); everything about J is absent
