@@ -312,8 +312,10 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
                     e1 = h->upd_ev[h->upd_used++];
                     GN_HIP(hipEventRecord(e0, h->stream));
                 }
-                if (use_mfma && lvl0) {
-                    // the J2 columns in 32-column blocks, the carried right-hand side (always the 32 j + 1-th column) on its own
+                if (use_mfma && lvl0 && (ntrail - 1) % 32 == 0) {
+                    // the J2 columns fill whole 32-column blocks and the carried right-hand side would take a block of its own
+                    // (the 32 j + 1-th column: every panel of C2): it gets its own routine as the last block index instead.
+                    // With a partial last block (C3: 24 columns) it simply rides in that block.
                     a.skip_rhs = 1;
                     launch_update_v4(h->plan.RPL, a, L.groups, ntrail - 1, (int)P.batch, h->stream);
                 } else if (use_mfma) launch_update_v4(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);

@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2m; mkdir -p $O
+O=${1:-gpurun_out/measure}; mkdir -p $O
 echo "[1] bench default"; python3 bench.py > $O/c2.json 2> $O/c2.err
 echo "[2] kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.py --steps 3 --warmup 1 --cpu-budget 0 > $O/c2_under_rocprof.json 2> $O/ks.err
 cp $O/ks/*/*kernel_stats.csv $O/c2_kernel_stats_bench_steps3.csv
