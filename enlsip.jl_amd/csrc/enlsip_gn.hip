@@ -102,21 +102,47 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     P.npan_max = (int)((kpmax + PB - 1) / PB);
     long long running = 0;
     P.panels.resize(P.npan_max);
+    // panel pairs (gn_kernels_caqr.hpp): from three panels on; the reflector-by-reflector A/B path keeps the plain sweep
+    P.pair = h->pair_enabled && !(h->flags & ENLSIP_GN_UPDATE_REFLECTORS) && P.npan_max >= 3;
+    const long long mpad = rup(std::max<long long>(m, 1), 32);    // NOT ldw: the skew rows are never touched
     for (int k = 0; k < P.npan_max; ++k) {
-        int nb = (int)(rup(std::max<long long>(m, 1), 32) / 32) - k;  // 32-row blocks from row 32k to the padded m (NOT ldw: the skew rows are never touched)
-        long long S = 32;
-        int level = 0;
-        while (true) {
+        const bool second = P.pair && (k & 1);                    // second panel of the pair (k - 1, k): keeps the first one's tiles
+        const long long anchor = 32LL * (k - (second ? 1 : 0));   // first row of tile 0
+        const int nb0 = (int)((mpad - anchor) / 32);              // 32-row blocks from the anchor to the padded m
+        const int ntiles = (nb0 + P.F - 1) / P.F;
+        const int last_units = nb0 - (ntiles - 1) * P.F;          // blocks of the last tile
+        auto push = [&](int level, int mode, long long base, int skip, int nblocks, int groups, long long S) {
             LevelPlan L;
-            L.level = level;
-            L.nblocks = nb;
-            L.groups = (nb + P.F - 1) / P.F;
-            L.S = S;
+            L.level = level; L.mode = mode; L.base = base; L.skip = skip;
+            L.nblocks = nblocks; L.groups = groups; L.S = S;
             L.tOff = running;
-            running += L.groups;
+            running += groups;
             P.panels[k].levels.push_back(L);
-            if (L.groups <= 1) break;
-            nb = L.groups;
+        };
+        // level 0: the tiles (a tile that has no row of the second panel still gets its — zero — T block: the pair update indexes
+        // T by tile)
+        push(0, 0, anchor, second ? 1 : 0, nb0, ntiles, 32);
+        if (ntiles <= 1) continue;
+        int level = 1, nb;
+        long long S = 32LL * P.F, base = 32LL * k;
+        if (!second) nb = ntiles;
+        else {
+            // first tree level of the second panel: per tile the new R factor (rows 32..63) and, from tile 1 on, the rows 0..31
+            // the first panel's tree left behind (dense in these columns): mode 2
+            const int nblocks1 = (ntiles - (last_units == 1 ? 1 : 0)) + (ntiles - 1);
+            const int groups1 = (nblocks1 + P.F - 1) / P.F;
+            push(1, 2, anchor, 0, nblocks1, groups1, S);
+            if (groups1 <= 1) continue;
+            // group leaders: blocks F q of level 1 = (tile (F / 2) q, rows 32..63)
+            nb = groups1;
+            S = S * (P.F / 2);
+            level = 2;
+        }
+        while (true) {
+            const int groups = (nb + P.F - 1) / P.F;
+            push(level, 1, base, 0, nb, groups, S);
+            if (groups <= 1) break;
+            nb = groups;
             S *= P.F;
             ++level;
         }
@@ -245,6 +271,7 @@ static CaqrArgs caqr_args(enlsip_gn_handle h, int k, const LevelPlan& L) {
     a.panel = k; a.level = L.level; a.F = P.F; a.nblocks = L.nblocks; a.S = L.S; a.tOff = L.tOff;
     a.W = h->W; a.sW = P.sW; a.Tbuf = h->Tbuf; a.sT = P.sT; a.state = h->state;
     a.ext_cols = 0; a.C = nullptr; a.sC = 0; a.reverse = 0;
+    a.mode = L.mode; a.base = L.base; a.skip = L.skip; a.win = 0; a.pair = 0; a.tOff2 = 0;
     return a;
 }
 
@@ -288,9 +315,108 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
     const int npan = (kp_launch + PB - 1) / PB;
     const bool use_mfma = !(h->flags & ENLSIP_GN_UPDATE_REFLECTORS);
-    for (int k = 0; k < npan; ++k) {
+    const double mpad = (double)rup(std::max<long long>(P.m, 1), 32);
+    // the launch shape is the widest J2 of the batch; narrower ones exist only when some constraint matrix was rank deficient
+    // (second attempt of solve_dev) or when the caller's problems differ
+    const bool mixed = n2_launch != (int)(P.n - P.kA);
+    // HIP events around the level-0 far updates (the dominant kernel) when profiling is on; `bytes` = SURVEY 8d's
+    // B_trail = 8 (2 m_k n_k + m_k b + b^2) of every panel the launch applies, on the columns it applies them to
+    auto timed = [&](double bytes, auto&& launch) -> int {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profiling) {
+            if (h->upd_used + 2 > h->upd_ev.size()) {
+                for (int q = 0; q < 2; ++q) {
+                    hipEvent_t e;
+                    GN_HIP(hipEventCreate(&e));
+                    h->upd_ev.push_back(e);
+                }
+            }
+            e0 = h->upd_ev[h->upd_used++];
+            e1 = h->upd_ev[h->upd_used++];
+            GN_HIP(hipEventRecord(e0, h->stream));
+        }
+        launch();
+        if (e1) {
+            GN_HIP(hipEventRecord(e1, h->stream));
+            h->upd_bytes += (double)P.batch * bytes;
+            h->upd_launch_bytes.push_back((double)P.batch * bytes);
+        }
+        return 0;
+    };
+    auto btrail = [&](int k, double ncols) { const double mk = mpad - (double)k * PB; return 8.0 * (2.0 * mk * ncols + mk * PB + PB * PB); };
+    // the MFMA update of every trailing column of the window; with the J2 columns filling whole 32-column blocks the carried
+    // right-hand side (the 32 j + 1-th column: every panel of C2) would take a block of its own: it gets its own routine as the
+    // last block index instead.  With a partial last block (C3: 24 columns) it simply rides in that block.
+    auto update_l0 = [&](CaqrArgs a, const LevelPlan& L, int ncols_window, int ncols_grid) {
+        if ((ncols_window - 1) % 32 == 0) {
+            a.skip_rhs = 1;
+            launch_update_v4(h->plan.RPL, a, L.groups, ncols_grid - 1, (int)P.batch, h->stream);
+        } else launch_update_v4(h->plan.RPL, a, L.groups, ncols_grid, (int)P.batch, h->stream);
+    };
+    for (int k = 0; k < npan;) {
+        if (h->debug_maxpan >= 0 && k >= h->debug_maxpan) break;   // ENLSIP_GN_DEBUG_MAXPAN: stop the sweep (debugging aid)
         const int bwk = std::min(PB, kp_launch - k * PB);
         const int ntrail = n2_launch + 1 - (k * PB + bwk);  // trailing columns incl. the augmented one
+        if (P.pair && use_mfma && !(k & 1) && k + 1 < npan) {
+            // ---- panel pair (k, k + 1): tiles shared, ONE pass over the far trailing columns for both (gn_kernels_caqr.hpp) ----
+            const int kb = k + 1;
+            const auto& LA = P.panels[k].levels;
+            const auto& LB = P.panels[kb].levels;
+            const int bwb = std::min(PB, kp_launch - kb * PB);
+            const int nfar = ntrail - bwb;                   // columns beyond the pair, incl. the augmented one (>= 1)
+            auto live = [&](int st) { return h->debug_stage < 0 || st <= h->debug_stage; };   // ENLSIP_GN_DEBUG_STAGE (debugging aid)
+            if (live(0)) {   // level 0 of the first panel, applied to the second panel's columns only
+                CaqrArgs a = caqr_args(h, k, LA[0]);
+                launch_factor(h, a, LA[0].groups);
+                a.win = 1;
+                launch_update_v4(h->plan.RPL, a, LA[0].groups, bwb, (int)P.batch, h->stream);
+            }
+            if (live(1)) {   // level 0 of the second panel: the same tiles without their first 32 rows
+                CaqrArgs a = caqr_args(h, kb, LB[0]);
+                launch_factor(h, a, LB[0].groups);
+            }
+            for (size_t li = 1; li < LA.size() && live(2); ++li) {      // tree of the first panel, applied to the second panel's columns
+                CaqrArgs a = caqr_args(h, k, LA[li]);
+                launch_factor(h, a, LA[li].groups);
+                a.win = 1;
+                launch_update_v4(h->plan.RPL, a, LA[li].groups, bwb, (int)P.batch, h->stream);
+            }
+            for (size_t li = 1; li < LB.size() && live(3); ++li) {      // tree of the second panel
+                CaqrArgs a = caqr_args(h, kb, LB[li]);
+                launch_factor(h, a, LB[li].groups);
+            }
+            // far columns: both level-0 reflectors in one pass (a problem whose J2 ends inside the pair has more far columns
+            // than the launch shape says: the grid covers ntrail, workgroups past a problem's last column exit at once)
+            if (!live(4)) {
+            } else if (h->pair_debug) {    // A/B: the same pair geometry, far columns in two plain passes (first panel, then second)
+                CaqrArgs a = caqr_args(h, k, LA[0]);
+                a.win = 2;
+                update_l0(a, LA[0], nfar, ntrail);
+                CaqrArgs b0 = caqr_args(h, kb, LB[0]);
+                if (live(5)) update_l0(b0, LB[0], nfar, nfar);
+            } else {
+                CaqrArgs a = caqr_args(h, k, LA[0]);
+                a.win = 2; a.pair = 1; a.tOff2 = LB[0].tOff;
+                int rc = timed(btrail(k, nfar) + btrail(kb, nfar), [&] { update_l0(a, LA[0], nfar, ntrail); });
+                if (rc) return rc;
+                if (mixed) {        // problems whose J2 ends before the second panel: the first panel alone, every trailing column
+                    a.pair = 2;
+                    update_l0(a, LA[0], nfar, ntrail);
+                }
+            }
+            for (size_t li = 1; li < LA.size() && live(6); ++li) {
+                CaqrArgs a = caqr_args(h, k, LA[li]);
+                a.win = 2;
+                launch_update_v4(h->plan.RPL, a, LA[li].groups, ntrail, (int)P.batch, h->stream);
+            }
+            for (size_t li = 1; li < LB.size() && live(7); ++li) {
+                CaqrArgs a = caqr_args(h, kb, LB[li]);
+                launch_update_v4(h->plan.RPL, a, LB[li].groups, nfar, (int)P.batch, h->stream);
+            }
+            k += 2;
+            continue;
+        }
+        // ---- one panel ----
         // last panel narrower than 32 with d as the only trailing column: d rides through the factor kernels
         const bool passenger = (ntrail == 1 && bwk < PB && kp_launch == n2_launch);
         for (const LevelPlan& L : P.panels[k].levels) {
@@ -298,35 +424,14 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             a.npass = passenger ? 1 : 0;
             launch_factor(h, a, L.groups);
             if (ntrail > 0 && !passenger) {
-                const bool lvl0 = (L.level == 0);
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (h->profiling && lvl0) {
-                    if (h->upd_used + 2 > h->upd_ev.size()) {
-                        for (int q = 0; q < 2; ++q) {
-                            hipEvent_t e;
-                            GN_HIP(hipEventCreate(&e));
-                            h->upd_ev.push_back(e);
-                        }
-                    }
-                    e0 = h->upd_ev[h->upd_used++];
-                    e1 = h->upd_ev[h->upd_used++];
-                    GN_HIP(hipEventRecord(e0, h->stream));
-                }
-                if (use_mfma && lvl0 && (ntrail - 1) % 32 == 0) {
-                    // the J2 columns fill whole 32-column blocks and the carried right-hand side would take a block of its own
-                    // (the 32 j + 1-th column: every panel of C2): it gets its own routine as the last block index instead.
-                    // With a partial last block (C3: 24 columns) it simply rides in that block.
-                    a.skip_rhs = 1;
-                    launch_update_v4(h->plan.RPL, a, L.groups, ntrail - 1, (int)P.batch, h->stream);
+                if (use_mfma && L.level == 0) {
+                    int rc = timed(btrail(k, ntrail), [&] { update_l0(a, L, ntrail, ntrail); });
+                    if (rc) return rc;
                 } else if (use_mfma) launch_update_v4(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
                 else launch_update_refl(h, a, L.groups, ntrail);
-                if (e1) {
-                    GN_HIP(hipEventRecord(e1, h->stream));
-                    const double mk = (double)(rup(std::max<long long>(P.m, 1), 32) - k * PB);
-                    h->upd_bytes += (double)P.batch * 8.0 * (2.0 * mk * ntrail + mk * PB + PB * PB);
-                }
             }
         }
+        ++k;
     }
     GN_HIP(hipGetLastError());
     return 0;
@@ -569,6 +674,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         }
         h->upd_used = 0;
         h->upd_bytes = 0.0;
+        h->upd_launch_bytes.clear();
     }
     auto mark = [&](int i) { if (h->profiling) (void)hipEventRecord(h->ev[i], s); };
 
@@ -724,6 +830,13 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             h->cu_count = prop.multiProcessorCount;
         h->trace = getenv("ENLSIP_GN_TRACE") != nullptr;
+        const char* pp = getenv("ENLSIP_GN_PAIR");            // 0: plain sweep, one panel per pass over the trailing matrix (A/B)
+        if (pp && pp[0] == '0') h->pair_enabled = false;
+        if (pp && pp[0] == '2') h->pair_debug = true;         // 2: pair geometry, but the far columns in two plain passes (A/B)
+        const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");
+        if (dm) h->debug_maxpan = atoi(dm);
+        const char* ds = getenv("ENLSIP_GN_DEBUG_STAGE");
+        if (ds) h->debug_stage = atoi(ds);
         const char* pl = getenv("ENLSIP_GN_PIPELINE");       // 0: never split a batch over two streams
         if (pl && pl[0] == '0') h->pipeline = false;
         if (pl && pl[0] == '1') h->pipeline_forced = true;    // 1: split even the small uniform shapes (A/B)
@@ -802,6 +915,19 @@ int enlsip_gn_get_stage_ms(enlsip_gn_handle h, float* ms) {
     if (!h) return -1;
     if (!ms) return -2;
     for (int i = 0; i < ENLSIP_GN_STAGE_COUNT; ++i) ms[i] = h->stage_ms[i];
+    return 0;
+}
+
+// debugging aid (not part of include/enlsip_gn.h): the working matrix W (ldw x (n + 1)) of problem `prob` as it stands
+int enlsip_gn_debug_copy_W(enlsip_gn_handle h, int64_t prob, double* out, int64_t* ldw_out, int64_t cap_doubles) {
+    if (!h || !h->have_plan) return -1;
+    const Plan& P = h->plan;
+    if (ldw_out) *ldw_out = P.ldw;
+    const size_t need = (size_t)P.ldw * (P.n + 1);
+    if (!out || (size_t)cap_doubles < need) return -3;
+    GN_HIP(hipSetDevice(h->device));
+    GN_HIP(hipStreamSynchronize(h->stream));
+    GN_HIP(hipMemcpy(out, h->W + prob * P.sW, need * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -16,6 +16,9 @@ struct LevelPlan {
     int groups;       // workgroups (= blocks of the next level)
     long long S;      // block stride (rows)
     long long tOff;   // first T block index
+    int mode = 0;     // row geometry (CaqrArgs::mode): 0 level-0 tiles, 1 plain tree level, 2 first tree level of a pair's second panel
+    long long base = 0;   // row of block 0
+    int skip = 0;     // level 0: leading 32-row units of every tile that belong to the pair's first panel
 };
 struct PanelPlan {
     std::vector<LevelPlan> levels;
@@ -28,6 +31,7 @@ struct Plan {
     int F = 16;          // blocks per group
     int ldw = 0, ldr = 0;
     int npan_max = 0;    // panels if n2 = n
+    bool pair = false;   // panels (2K, 2K+1) share their tiles and one pass over the far trailing columns (gn_kernels_caqr.hpp, "Panel pairs")
     long long nTblocks = 0;
     std::vector<PanelPlan> panels;
     // per-problem strides (elements)
@@ -86,6 +90,9 @@ struct enlsip_gn_context {
     // a child handle (own stream + workspace) driven by a host thread, so the latency-bound kernels of one half
     // overlap the bandwidth-bound kernels of the other.  Accessors route a problem index to the half that owns it.
     enlsip_gn_context* child = nullptr;
+    bool pair_debug = false;
+    int debug_maxpan = -1, debug_stage = -1;
+    bool pair_enabled = true;           // ENLSIP_GN_PAIR=0: one panel per pass over the trailing matrix
     bool pipeline = true;               // ENLSIP_GN_PIPELINE=0 disables
     bool pipeline_forced = false;   // ENLSIP_GN_PIPELINE=1
     long long pipeline_min = 128;       // smallest batch that is split
@@ -121,6 +128,7 @@ struct enlsip_gn_context {
     std::vector<hipEvent_t> upd_ev;   // pairs around level-0 update launches
     size_t upd_used = 0;
     double upd_bytes = 0.0;
+    std::vector<double> upd_launch_bytes;   // per timed launch, same order as the event pairs
     float upd_avg_ms = 0.f;
     long long upd_launches = 0;
 };

@@ -210,12 +210,19 @@ __device__ __forceinline__ double wave_bcast(double x, int src_lane) {
 
 // LAPACK dlarfg without the safmin rescaling loop:
 // beta = -sign(alpha) * hypot(alpha, xnorm), tau = (beta - alpha) / beta, v = x / (alpha - beta)
+// The norm is taken from a plain sum of squares, so a column of norm below ~1e-140 has squares in (or under) the denormal
+// range: tau and v would no longer describe an orthogonal reflector (measured: v'v - 2 = 5e-8 at norm 1e-159).  Such columns
+// do occur: a tile whose content has just been rotated out exactly by the previous panel holds rounding dust, and the dust of
+// the dust of ... falls by 1e-16 per column (a stack of upper triangles — the TSQR combine stage — does this).  They are
+// treated as zero columns: H = I, the dust below the diagonal is dropped (callers store v = x * scale = 0), a perturbation of
+// 1e-140 in absolute terms, inside the magnitude range DESIGN.md section 2 states.
+constexpr double GN_TINY_NORM2 = 1e-280;
 struct Reflector {
     double beta, tau, scale;
 };
 __device__ __forceinline__ Reflector make_reflector(double alpha, double xnorm2) {
     Reflector r;
-    if (xnorm2 == 0.0) {
+    if (xnorm2 == 0.0 || alpha * alpha + xnorm2 < GN_TINY_NORM2) {
         r.beta = alpha;
         r.tau = 0.0;
         r.scale = 0.0;

@@ -43,7 +43,44 @@ struct CaqrArgs {
     int npass;          // factor kernel: 1 = the column right after a panel narrower than 32 (the carried right-hand side
                         // d, when it is the ONLY trailing column) rides through the factorisation as a passenger: it receives
                         // every reflector but is never factored, and no trailing-update launch is needed for the panel
+    // Row geometry of the level (see "Panel pairs" below): block q of the level starts at row
+    //   mode 0 / 1:  base + q * S                         (level 0: S = 32, base = first row of tile 0)
+    //   mode 2    :  base + ((q + 1) >> 1) * S + ((q + 1) & 1) * 32      (first tree level of a pair's second panel)
+    int mode;
+    long long base;
+    int skip;           // level 0: the first `skip` 32-row units of every tile do not belong to this panel (second panel of a pair: 1)
+    // trailing update only:
+    int win;            // 0: every trailing column; 1: only the columns of the NEXT panel (narrow update inside a pair);
+                        // 2: every trailing column BEYOND the next panel's columns (far update of a pair's first panel)
+    int pair;           // level-0 far update: 1 = the workgroup also applies the level-0 reflectors of panel + 1 (T blocks from
+                        // tOff2) to its block of C while it sits in registers: one pass over the trailing matrix for two panels
+    long long tOff2;
 };
+
+// ---------------------------------------------------------------------------------------------
+// Panel pairs (two panels per pass over the trailing matrix).
+// With b = 32 the trailing update moves 16 bytes per 8 flops: HBM bound.  Applying TWO panels' reflectors in one pass halves
+// that traffic, but in the plain CAQR sweep panel k + 1's tile reflectors do not commute with panel k's tree reflectors
+// (the tree mixes the first 32 rows of every tile, which panel k + 1's tiles would contain).  So the second panel of a
+// pair (a, b) keeps the tiles of a and simply leaves out their first 32 rows:
+//     level 0 of b : tile g = rows [anchor + TR g + 32, anchor + TR (g + 1)), reflector j's diagonal in tile slot 32 + j;
+//     level 1 of b : per tile the R factor just produced (rows 32..63 of the tile, upper triangular) AND, for tiles g >= 1,
+//                    the rows 0..31 left over from a (dense in b's columns once a's tree has been applied to them);
+//                    block order: (tile 0, rows 32..63), then (tile g, rows 0..31), (tile g, rows 32..63) for g = 1, 2, ...
+//                    = mode 2 above, dense blocks at odd q; higher levels combine the group leaders as usual.
+// Now level 0 of b (rows 32.. of every tile) and the tree of a (rows 0..31 of every tile) touch disjoint rows and commute:
+//     Q' = tree(b)' tree(a)' [L0(b)' L0(a)'],
+// and the bracket is tile-local: one workgroup applies both to its block of C between one load and one store.
+// ---------------------------------------------------------------------------------------------
+// width of the panel after the one that starts at J2 column r0 (0: there is none)
+__device__ __forceinline__ int caqr_next_bw(int kp, int r0) {
+    const int left = kp - (r0 + PB);
+    return left <= 0 ? 0 : (left < PB ? left : PB);
+}
+__device__ __forceinline__ long long caqr_block_row(const CaqrArgs& a, long long q) {
+    if (a.mode == 2) return a.base + ((q + 1) >> 1) * a.S + ((q + 1) & 1) * 32;
+    return a.base + q * a.S;
+}
 
 // ---------------------------------------------------------------------------------------------
 // panel factorisation of one group (tile or tree node)
@@ -88,11 +125,18 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 
     // Address = wave-uniform part (column, block pair i) + ONE per-lane offset: no per-slot address registers.
     const int rb = ln & 31;
     const int qh = ln >> 5;
-    const long long lane_off = (long long)qh * a.S + rb;
+    // row geometry (CaqrArgs): blocks 2 i and 2 i + 1 of the group sit S rows apart (modes 0, 1); in mode 2 the pair is
+    // (rows 32..63 of one tile, rows 0..31 of the NEXT tile) and the odd block is dense
+    const bool split = a.mode == 2;
+    const bool dns = split && qh == 1;
+    const long long lane_off = split ? (qh ? a.S : 32) + rb : (long long)qh * a.S + rb;
+    const long long u0 = a.base + (split ? ((long long)g * a.F / 2) * a.S : ((long long)g * a.F) * a.S);
+    const long long ustep = split ? a.S : 2 * a.S;
+    const int dsh = 32 * a.skip;                      // slot of reflector j's diagonal = j + dsh (level 0 of a pair's second panel: 32)
     auto ubase = [&](int c, int i) -> size_t {        // uniform
-        return (size_t)(col0 + c) * a.ldw + (size_t)(r0 + ((long long)g * a.F + 2 * i) * a.S);
+        return (size_t)(col0 + c) * a.ldw + (size_t)(u0 + i * ustep);
     };
-    auto bval = [&](int i) -> bool { return (long long)g * a.F + qh + 2 * i < a.nblocks; };
+    auto bval = [&](int i) -> bool { return (long long)g * a.F + qh + 2 * i < a.nblocks && qh + 2 * i >= a.skip; };
     // load the tile: a[cc][i] = element (slot ln + 64 i, column w + NW cc)
     double x[NC][RPL];
 #pragma unroll
@@ -101,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             // tree levels hold upper triangles; the passenger has entries in every row a reflector touches
-            const bool ok = (c < bwp) && bval(i) && (!tri || (c < bw ? rb <= c : rb < bw));
+            const bool ok = (c < bwp) && bval(i) && (!tri || dns || (c < bw ? rb <= c : rb < bw));
             x[cc][i] = ok ? W[ubase(c, i) + lane_off] : 0.0;
         }
     }
@@ -116,21 +160,22 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 
             if (j < bw) {
                 const int buf = j & 1;
                 if (w == jw) {
-                    // reflector of column j: pivot slot j lives in lane j, register 0
+                    // reflector of column j: pivot slot dj = j + dsh lives in lane dj, register 0
+                    const int dj = j + dsh;
                     double xn2 = 0.0;
 #pragma unroll
                     for (int i = 0; i < RPL; ++i)
-                        if (lnl + 64 * i > j) xn2 += x[jj][i] * x[jj][i];
+                        if (lnl + 64 * i > dj) xn2 += x[jj][i] * x[jj][i];
                     xn2 = wave_allsum(xn2);
-                    const double alpha = wave_bcast(x[jj][0], j);
+                    const double alpha = wave_bcast(x[jj][0], dj);
                     const Reflector h = make_reflector(alpha, xn2);
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) {
                         const int s = lnl + 64 * i;
-                        const double v = (s > j) ? x[jj][i] * h.scale : (s == j ? 1.0 : 0.0);
+                        const double v = (s > dj) ? x[jj][i] * h.scale : (s == dj ? 1.0 : 0.0);
                         vsh[buf][s] = v;
-                        if (s > j) x[jj][i] = v;
-                        if (s == j) x[jj][i] = h.beta;
+                        if (s > dj) x[jj][i] = v;
+                        if (s == dj) x[jj][i] = h.beta;
                     }
                     if (lnl == 0) taush[j] = h.tau;
                 }
@@ -171,7 +216,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 
         const int c = w + NW * cc;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const bool ok = (c < bwp) && bval(i) && (!tri || (c < bw ? rb <= c : rb < bw));
+            const bool ok = (c < bwp) && bval(i) && (!tri || dns || (c < bw ? rb <= c : rb < bw));
             if (ok) W[ubase(c, i) + lane_off] = x[cc][i];
         }
     }
@@ -223,8 +268,13 @@ __global__ __launch_bounds__(256) void k_caqr_update_refl(CaqrArgs a) {
         C = a.C + prob * a.sC;
         ncols = a.ext_cols;
     } else {
-        const int first = r0 + bw;             // J2-local index of the first trailing column
+        int first = r0 + bw;                   // J2-local index of the first trailing column
         ncols = st.n2 + 1 - first;             // includes the augmented column (local index n2)
+        if (a.win) {                           // pair: only / all but the next panel's columns
+            const int bwn = caqr_next_bw(st.kp, r0);
+            if (a.win == 1) ncols = bwn;
+            else { first += bwn; ncols -= bwn; }
+        }
         C = a.W + prob * a.sW + (size_t)(st.rankA + first) * a.ldw;
     }
     const int cbase = blockIdx.y * 32;
@@ -232,16 +282,18 @@ __global__ __launch_bounds__(256) void k_caqr_update_refl(CaqrArgs a) {
 
     const int rb = ln & 31;
     long long rowoff[RPL];
-    bool bval[RPL];
+    bool bval[RPL], dns[RPL];
     int qq[RPL];
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
         const int q = (ln >> 5) + 2 * i;
         const long long bidx = (long long)g * a.F + q;
         qq[i] = q;
-        bval[i] = bidx < a.nblocks;
-        rowoff[i] = r0 + bidx * a.S + rb;
+        bval[i] = bidx < a.nblocks && q >= a.skip;
+        dns[i] = a.mode == 2 && ((bidx + 1) & 1) == 0;
+        rowoff[i] = caqr_block_row(a, bidx) + rb;
     }
+    const int dsh = 32 * a.skip;
     double x[8][RPL];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
@@ -257,11 +309,11 @@ __global__ __launch_bounds__(256) void k_caqr_update_refl(CaqrArgs a) {
             double val = 0.0;
             if (bval[i]) {
                 if (!tri) {
-                    if (s > j) val = W[rowoff[i] + (size_t)(col0 + j) * a.ldw];
-                    else if (s == j) val = 1.0;
+                    if (s > j + dsh) val = W[rowoff[i] + (size_t)(col0 + j) * a.ldw];
+                    else if (s == j + dsh) val = 1.0;
                 } else {
                     if (qq[i] == 0) val = (rb == j) ? 1.0 : 0.0;
-                    else if (rb <= j) val = W[rowoff[i] + (size_t)(col0 + j) * a.ldw];
+                    else if (dns[i] || rb <= j) val = W[rowoff[i] + (size_t)(col0 + j) * a.ldw];
                 }
             }
             v[i] = val;

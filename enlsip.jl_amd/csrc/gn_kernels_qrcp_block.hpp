@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
     c.C = a.q.M + prob * a.q.sM;
     c.T = a.Tsb + prob * a.sTsb;
     const int d = jb & 1;                 // start one row early when jb is odd: every row pair is 16-byte aligned
-    c.tile_row0 = jb - d; c.r0 = jb - d; c.gblk0 = 0; c.S = 0;
+    c.tile_row0 = jb - d; c.r0 = jb - d; c.gblk0 = 0; c.S = 0; c.mode = 0;
+    c.T2 = nullptr; c.col02 = 0; c.bw2 = 0; c.dshift2 = 0;
     c.ldw = a.q.ldr; c.col0 = jb; c.bw = s; c.cb0 = cb0;
     c.rows_valid = kp - (jb - d);
     c.dshift = d;

@@ -67,8 +67,13 @@ struct V4Ctx {
     long long tile_row0, r0, gblk0, S;
     int ldw, col0, bw, cb0;
     int rows_valid;       // RMASK only: slots >= rows_valid do not exist (element granularity)
-    int dshift;           // level 0: the diagonal of reflector j sits in slot j + dshift (0 for the CAQR; the blocked
-                          // pivoted QR starts its units one row early when its first row is odd, for 16-byte alignment)
+    int dshift;           // level 0: the diagonal of reflector j sits in slot j + dshift (0 for the CAQR; 32 for the second panel
+                          // of a pair; the blocked pivoted QR starts its units one row early when its first row is odd, for
+                          // 16-byte alignment)
+    int mode;             // TRI: row geometry of the level (CaqrArgs::mode; r0 = base)
+    // NAP = 2: the second block reflector applied to the same block of C (level 0 of the pair's second panel)
+    const double* T2;
+    int col02, bw2, dshift2;
 };
 
 struct V4NoPost {         // default post-update hook: nothing
@@ -90,10 +95,13 @@ struct V4NoPost {         // default post-update hook: nothing
 //         16 ct + lq + 4 r) before they are stored.
 // GATHER = true: the block's 32 columns are arbitrary columns of C: coff[4 ct + r] is this lane's byte offset of
 //         column (16 ct + lq + 4 r) from c.C (the blocked pivoted QR updates only its still-active columns).
-template <int RPL, bool TRI, bool CFULL, int NGW, int NCT, bool RMASK = false, class Post = V4NoPost, bool GATHER = false>
+// NAP   = block reflectors applied one after the other to the block of C while it stays in registers (1, or 2 for a panel
+//         pair: c.T2 / col02 / bw2 / dshift2 describe the second one; level 0 only).
+template <int RPL, bool TRI, bool CFULL, int NGW, int NCT, bool RMASK = false, class Post = V4NoPost, bool GATHER = false, int NAP = 1>
 __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*stage)[V4_STAGE], double* W2l,
                                         const unsigned vmask = ~0u, const unsigned smask = ~0u, const Post& post = Post(),
                                         const unsigned* coff = nullptr) {
+    static_assert(NAP == 1 || !TRI, "pairs are applied at level 0 only");
     const int ln = lane_id();
     const int lr = ln & 15, lq = ln >> 4;
     const int it2 = w >> 1, ct2 = w & 1;             // W2 tile produced by this wave in the reduction step
@@ -103,15 +111,22 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     auto slot0 = [&](int g) -> int { return 32 * (w + 4 * g); };                              // first slot of the wave's unit g
     auto rowu = [&](int g) -> long long {            // uniform: global row of that slot
         if (!TRI) return c.tile_row0 + slot0(g);
-        return c.r0 + (c.gblk0 + (w + 4 * g)) * c.S;
+        const long long q = c.gblk0 + (w + 4 * g);
+        if (c.mode == 2) return c.r0 + ((q + 1) >> 1) * c.S + ((q + 1) & 1) * 32;
+        return c.r0 + q * c.S;
     };
+    auto ap_T = [&](int ai) -> const double* { return ai ? c.T2 : c.T; };
+    auto ap_col0 = [&](int ai) -> int { return ai ? c.col02 : c.col0; };
+    auto ap_bw = [&](int ai) -> int { return ai ? c.bw2 : c.bw; };
+    auto ap_dshift = [&](int ai) -> int { return ai ? c.dshift2 : c.dshift; };
+    const bool dense_unit = TRI && c.mode == 2 && (w & 1);   // mode 2: odd blocks are dense (gblk0 is even)
     auto cptr = [&](int g, int ct, int r) -> double* {
         if (GATHER) return (double*)((char*)(c.C + rowu(g)) + (coff[4 * ct + r] + 16u * (unsigned)lr));
         double* ub = c.C + (size_t)(c.cb0 + 16 * ct + 4 * r) * c.ldw + rowu(g);      // uniform
         return (double*)((char*)ub + lane_byte);
     };
-    auto vptr = [&](int g, int ks) -> const double* {
-        const double* ub = c.Wm + (size_t)(c.col0 + 4 * ks) * c.ldw + rowu(g);       // uniform
+    auto vptr = [&](int ai, int g, int ks) -> const double* {
+        const double* ub = c.Wm + (size_t)(ap_col0(ai) + 4 * ks) * c.ldw + rowu(g);       // uniform
         return (const double*)((const char*)ub + lane_byte);
     };
 
@@ -141,15 +156,16 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             }
     };
     // V operands are fetched in halves of 4 contraction steps: vh[k4] = V[row pair][vcol 16 h + 4 k4 + lq]
-    auto issue_v = [&](int g, int h, v4_d2 (&vh)[4]) {
+    auto issue_v = [&](int ai, int g, int h, v4_d2 (&vh)[4]) {
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             if (V4_ABLATE == 2 || V4_ABLATE == 5) vh[k4] = (v4_d2){(double)(g + k4), 1.0};
-            else vh[k4] = *(const v4_d2*)vptr(g, 4 * h + k4);
+            else vh[k4] = *(const v4_d2*)vptr(ai, g, 4 * h + k4);
         }
     };
-    auto finish_v = [&](int g, int h, v4_d2 (&vh)[4]) {   // structure of V: unit trapezoid / identity + triangles
+    auto finish_v = [&](int ai, int g, int h, v4_d2 (&vh)[4]) {   // structure of V: unit trapezoid / identity + triangles
         const int s0 = slot0(g) + 2 * lr;
+        const int dsh = ap_dshift(ai);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const int j = 16 * h + 4 * k4 + lq;
@@ -158,272 +174,368 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                 const int s = s0 + p;
                 double x = vh[k4][p];
                 if (!TRI) {
-                    if (g == 0) x = (s > j + c.dshift) ? x : ((s == j + c.dshift) ? 1.0 : 0.0);   // only units 0..3 can meet the diagonal
+                    if (g == 0) x = (s > j + dsh) ? x : ((s == j + dsh) ? 1.0 : 0.0);   // only units 0..3 can meet the diagonal (dshift <= 32)
                 } else {
-                    const double tri = ((s & 31) <= j) ? x : 0.0;
+                    const double tri = (dense_unit || (s & 31) <= j) ? x : 0.0;
                     x = (g == 0 && s < PB) ? ((s == j) ? 1.0 : 0.0) : tri;
                 }
-                if (!CFULL) x = (j < c.bw && (!RMASK || s < c.rows_valid)) ? x : 0.0;
+                if (!CFULL) x = (j < ap_bw(ai) && (!RMASK || s < c.rows_valid)) ? x : 0.0;
                 vh[k4][p] = x;
             }
         }
     };
 
-    // ---- product 1: per-wave partial W1 = V' C ------------------------------------------------------------
-    V4_STAMP(0);
-    v4_d4 acc[2][2];
+    // One pass per block reflector (NAP of them); the block of C stays in registers from the loads of the first pass to the
+    // stores of the last one: as loaded (row-pair quads cp) through product 1 of the first pass, in the accumulator layout of
+    // product 2 (cf) from then on.  Later passes build their transpose images from cf with 64-bit LDS stores and the rows of
+    // a unit permuted (row 2 lr + p -> slot lr + 16 p, in BOTH images: the contraction index of product 1 may be any
+    // bijection), so that no pass needs the block in two register layouts at once.
+    v4_d4 cf[NAP > 1 ? (NGW > 0 ? NGW : 1) : 1][2][2];
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int ai = 0; ai < NAP; ++ai) {
+        const bool first_app = (ai == 0), last_app = (ai == NAP - 1);
+        // ---- product 1: per-wave partial W1 = V' C ------------------------------------------------------------
+        if (first_app) V4_STAMP(0);
+        v4_d4 acc[2][2];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[it][ct] = (v4_d4){0.0, 0.0, 0.0, 0.0};
-    // T' operand of the fused reduction step: A[i = k][kk = l] = T[l][k] (upper triangular)
-    double tA[8];
-    if (NGW == 0) {
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) tA[ks] = c.T[4 * ks + lq + (16 * it2 + lr) * PB];
-    }
-    if (NGW > 0) {
-        v4_d2 vp[2][4];
-        issue_v(0, 0, vp[0]);
-        issue_v(0, 1, vp[1]);
-        issue_c(0);
-        if (NGW > 1) issue_c(1);
+            for (int ct = 0; ct < 2; ++ct) acc[it][ct] = (v4_d4){0.0, 0.0, 0.0, 0.0};
+        // T' operand of the fused reduction step: A[i = k][kk = l] = T[l][k] (upper triangular)
+        double tA[8];
+        if (NGW == 0) {
 #pragma unroll
-        for (int g = 0; g < NGW; ++g) {
-            // transpose images of unit g (the previous unit's reads were issued before: LDS keeps a wave's order)
-            finish_v(g, 0, vp[0]);
-            finish_v(g, 1, vp[1]);
-            finish_c(g);
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) *(v4_d2*)&Vs[(4 * ks + lq) * V4_LD + 2 * lr] = vp[ks >> 2][ks & 3];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) *(v4_d2*)&Cs[(16 * ct + lq + 4 * r) * V4_LD + 2 * lr] = cp[g][ct][r];
-            // next operands: V one unit ahead (same registers), C two units ahead (its own registers)
-            if (g + 1 < NGW) {
-                issue_v(g + 1, 0, vp[0]);
-                issue_v(g + 1, 1, vp[1]);
+            for (int ks = 0; ks < 8; ++ks) tA[ks] = ap_T(ai)[4 * ks + lq + (16 * it2 + lr) * PB];
+        }
+        if (NGW > 0) {
+            v4_d2 vp[2][4];
+            issue_v(ai, 0, 0, vp[0]);
+            issue_v(ai, 0, 1, vp[1]);
+            if (first_app) {
+                issue_c(0);
+                if (NGW > 1) issue_c(1);
             }
-            if (g + 2 < NGW) issue_c(g + 2);
-            if (g == NGW - 1) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) tA[ks] = c.T[4 * ks + lq + (16 * it2 + lr) * PB];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < NGW; ++g) {
+                // transpose images of unit g (the previous unit's reads were issued before: LDS keeps a wave's order)
+                finish_v(ai, g, 0, vp[0]);
+                finish_v(ai, g, 1, vp[1]);
+                if (first_app) {
+                    finish_c(g);
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                double av[2][4], bv[2][4];
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const int kr = 16 * kh + 4 * k4 + lq;            // row of the unit = contraction index
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) av[it][k4] = Vs[(16 * it + lr) * V4_LD + kr];
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) bv[ct][k4] = Cs[(16 * ct + lr) * V4_LD + kr];
-                }
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
+                    for (int ks = 0; ks < 8; ++ks) *(v4_d2*)&Vs[(4 * ks + lq) * V4_LD + 2 * lr] = vp[ks >> 2][ks & 3];
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                        for (int k4 = 0; k4 < 4; ++k4) {
-                            if (V4_ABLATE == 4) acc[it][ct][k4] += av[it][k4] + bv[ct][k4];
-                            else acc[it][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[it][k4], bv[ct][k4], acc[it][ct], 0, 0, 0);
-                        }
+                        for (int r = 0; r < 4; ++r) *(v4_d2*)&Cs[(16 * ct + lq + 4 * r) * V4_LD + 2 * lr] = cp[g][ct][r];
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) Vs[(4 * ks + lq) * V4_LD + 16 * p + lr] = vp[ks >> 2][ks & 3][p];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) Cs[(16 * ct + lq + 4 * r) * V4_LD + 16 * p + lr] = cf[g][p][ct][r];
+                }
+                // next operands: V one unit ahead (same registers), C two units ahead (its own registers)
+                if (g + 1 < NGW) {
+                    issue_v(ai, g + 1, 0, vp[0]);
+                    issue_v(ai, g + 1, 1, vp[1]);
+                }
+                if (first_app && g + 2 < NGW) issue_c(g + 2);
+                if (g == NGW - 1) {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) tA[ks] = ap_T(ai)[4 * ks + lq + (16 * it2 + lr) * PB];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    double av[2][4], bv[2][4];
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const int kr = 16 * kh + 4 * k4 + lq;            // row of the unit = contraction index
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) av[it][k4] = Vs[(16 * it + lr) * V4_LD + kr];
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) bv[ct][k4] = Cs[(16 * ct + lr) * V4_LD + kr];
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                            for (int k4 = 0; k4 < 4; ++k4) {
+                                if (V4_ABLATE == 4) acc[it][ct][k4] += av[it][k4] + bv[ct][k4];
+                                else acc[it][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[it][k4], bv[ct][k4], acc[it][ct], 0, 0, 0);
+                            }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
-    }
-    V4_STAMP(1);
-    v4_d2 vb[2][4];                                      // ring over (unit, half)
-    if (NGW > 0) issue_v(0, 0, vb[0]);                   // travels during the reduction step
+        if (first_app) V4_STAMP(1);
+        v4_d2 vb[2][4];                                      // ring over (unit, half)
+        if (NGW > 0) issue_v(ai, 0, 0, vb[0]);               // travels during the reduction step
 
-    // ---- reduction over waves fused with W2 = -T' W1 (the partial goes to the wave's own stage) ----------
+        // ---- reduction over waves fused with W2 = -T' W1 (the partial goes to the wave's own stage) ----------
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[w][(16 * it + lq + 4 * r) * PB + 16 * ct + lr] = acc[it][ct][r];
-    V4_STAMP(2);
-    __syncthreads();
-    V4_STAMP(3);
-    {
-        v4_d4 t = (v4_d4){0.0, 0.0, 0.0, 0.0};
+                for (int r = 0; r < 4; ++r) stage[w][(16 * it + lq + 4 * r) * PB + 16 * ct + lr] = acc[it][ct][r];
+        if (first_app) V4_STAMP(2);
+        __syncthreads();
+        if (first_app) V4_STAMP(3);
+        {
+            v4_d4 t = (v4_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int l = 4 * ks + lq, k = 16 * it2 + lr;
-            const int o = l * PB + 16 * ct2 + lr;
-            const double b = (stage[0][o] + stage[1][o]) + (stage[2][o] + stage[3][o]);
-            const double ta = (l <= k && k < c.bw) ? tA[ks] : 0.0;
-            t = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, b, t, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) {
+                const int l = 4 * ks + lq, k = 16 * it2 + lr;
+                const int o = l * PB + 16 * ct2 + lr;
+                const double b = (stage[0][o] + stage[1][o]) + (stage[2][o] + stage[3][o]);
+                const double ta = (l <= k && k < ap_bw(ai)) ? tA[ks] : 0.0;
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, b, t, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W2l[(16 * it2 + lq + 4 * r) * PB + ((16 * ct2 + lr) ^ (16 * (lq & 1)))] = -t[r];   // swizzled, see the read
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) W2l[(16 * it2 + lq + 4 * r) * PB + ((16 * ct2 + lr) ^ (16 * (lq & 1)))] = -t[r];   // swizzled, see the read
-    }
-    __syncthreads();
-    V4_STAMP(4);
+        __syncthreads();
+        if (first_app) V4_STAMP(4);
 
-    // ---- product 2: D^T[col][row pair] += W2^T V^T, even and odd rows of each unit, stored at once ----------
+        // ---- product 2: D^T[col][row pair] += W2^T V^T, even and odd rows of each unit; stored by the last pass,
+        //      back into the registers otherwise ---------------------------------------------------------------------
 #pragma unroll
-    for (int g = 0; g < NGW; ++g) {
-        v4_d4 fr[2][2];                                  // [p][ct]
+        for (int g = 0; g < NGW; ++g) {
+            v4_d4 fr[2][2];                                  // [p][ct]
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int ct = NCT; ct < 2; ++ct) fr[p][ct] = (v4_d4){0.0, 0.0, 0.0, 0.0};
+                for (int ct = NCT; ct < 2; ++ct) fr[p][ct] = (v4_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) fr[p][ct] = (v4_d4){cp[g][ct][0][p], cp[g][ct][1][p], cp[g][ct][2][p], cp[g][ct][3][p]};
+                for (int ct = 0; ct < NCT; ++ct) {
+                    if (first_app) fr[p][ct] = (v4_d4){cp[g][ct][0][p], cp[g][ct][1][p], cp[g][ct][2][p], cp[g][ct][3][p]};
+                    else fr[p][ct] = cf[g][p][ct];
+                }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int u = 2 * g + h;                     // piece index; piece u + 1 is fetched while u is used
-            if (u + 1 < 2 * NGW) issue_v((u + 1) >> 1, (u + 1) & 1, vb[(u + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            finish_v(g, h, vb[u & 1]);
+            for (int h = 0; h < 2; ++h) {
+                const int u = 2 * g + h;                     // piece index; piece u + 1 is fetched while u is used
+                if (u + 1 < 2 * NGW) issue_v(ai, (u + 1) >> 1, (u + 1) & 1, vb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                finish_v(ai, g, h, vb[u & 1]);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                double a2[4];
+                for (int ct = 0; ct < NCT; ++ct) {
+                    double a2[4];
 #pragma unroll
-                // A[i = col][k]; rows k and k + 1 (the two 16-lane groups of a half-wave) are 256 B apart = same banks, so odd
-                // rows are stored with their two column halves exchanged: conflict-free ds_read_b64
-                for (int k4 = 0; k4 < 4; ++k4) a2[k4] = W2l[(16 * h + 4 * k4 + lq) * PB + ((16 * ct + lr) ^ (16 * (lq & 1)))];
+                    // A[i = col][k]; rows k and k + 1 (the two 16-lane groups of a half-wave) are 256 B apart = same banks, so odd
+                    // rows are stored with their two column halves exchanged: conflict-free ds_read_b64
+                    for (int k4 = 0; k4 < 4; ++k4) a2[k4] = W2l[(16 * h + 4 * k4 + lq) * PB + ((16 * ct + lr) ^ (16 * (lq & 1)))];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) {
+                            if (V4_ABLATE == 4) fr[p][ct][k4] += a2[k4] + vb[u & 1][k4][p];
+                            else fr[p][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[k4], vb[u & 1][k4][p], fr[p][ct], 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!last_app) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        if (V4_ABLATE == 4) fr[p][ct][k4] += a2[k4] + vb[u & 1][k4][p];
-                        else fr[p][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[k4], vb[u & 1][k4][p], fr[p][ct], 0, 0, 0);
-                    }
+                    for (int ct = 0; ct < 2; ++ct) cf[g][p][ct] = fr[p][ct];
+                continue;
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        post(g, fr);
+            post(g, fr);
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (V4_ABLATE == 3 || V4_ABLATE == 5) {
-                    if (fr[0][ct][r] == 1.2345e301) c.C[0] = fr[1][ct][r];
-                } else if (CFULL || ((smask >> (4 * ct + r)) & 1u)) {
-                    if (!RMASK) {
-                        __builtin_nontemporal_store((v4_d2){fr[0][ct][r], fr[1][ct][r]}, (v4_d2*)cptr(g, ct, r));
-                    } else {
-                        const int s0 = slot0(g) + 2 * lr;
-                        if (s0 + 1 < c.rows_valid) *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
-                        else if (s0 < c.rows_valid) *cptr(g, ct, r) = fr[0][ct][r];
+                for (int r = 0; r < 4; ++r) {
+                    if (V4_ABLATE == 3 || V4_ABLATE == 5) {
+                        if (fr[0][ct][r] == 1.2345e301) c.C[0] = fr[1][ct][r];
+                    } else if (CFULL || ((smask >> (4 * ct + r)) & 1u)) {
+                        if (!RMASK) {
+                            __builtin_nontemporal_store((v4_d2){fr[0][ct][r], fr[1][ct][r]}, (v4_d2*)cptr(g, ct, r));
+                        } else {
+                            const int s0 = slot0(g) + 2 * lr;
+                            if (s0 + 1 < c.rows_valid) *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
+                            else if (s0 < c.rows_valid) *cptr(g, ct, r) = fr[0][ct][r];
+                        }
                     }
                 }
-            }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     V4_STAMP(5);
 }
 
-template <int RPL, bool TRI, bool CFULL, int NCT, bool RMASK = false, class Post = V4NoPost, bool GATHER = false>
+template <int RPL, bool TRI, bool CFULL, int NCT, bool RMASK = false, class Post = V4NoPost, bool GATHER = false, int NAP = 1>
 __device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, double (*stage)[V4_STAGE], double* W2l,
                                             const unsigned vmask = ~0u, const unsigned smask = ~0u, const Post& post = Post(),
                                             const unsigned* coff = nullptr) {
     constexpr int NG = RPL / 2;
-    // every variant executes exactly two workgroup barriers, so waves of one workgroup may take different ones
-    if (ngw >= NG) v4_body<RPL, TRI, CFULL, NG, NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
-    else if (NG > 3 && ngw == 3) v4_body<RPL, TRI, CFULL, (NG > 3 ? 3 : 0), NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
-    else if (NG > 2 && ngw == 2) v4_body<RPL, TRI, CFULL, (NG > 2 ? 2 : 0), NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
-    else if (NG > 1 && ngw == 1) v4_body<RPL, TRI, CFULL, (NG > 1 ? 1 : 0), NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
-    else v4_body<RPL, TRI, CFULL, 0, NCT, RMASK, Post, GATHER>(c, w, stage, W2l, vmask, smask, post, coff);
+    // every variant executes exactly two workgroup barriers per block reflector, so waves of one workgroup may take different ones
+    if (ngw >= NG) v4_body<RPL, TRI, CFULL, NG, NCT, RMASK, Post, GATHER, NAP>(c, w, stage, W2l, vmask, smask, post, coff);
+    else if (NG > 3 && ngw == 3) v4_body<RPL, TRI, CFULL, (NG > 3 ? 3 : 0), NCT, RMASK, Post, GATHER, NAP>(c, w, stage, W2l, vmask, smask, post, coff);
+    else if (NG > 2 && ngw == 2) v4_body<RPL, TRI, CFULL, (NG > 2 ? 2 : 0), NCT, RMASK, Post, GATHER, NAP>(c, w, stage, W2l, vmask, smask, post, coff);
+    else if (NG > 1 && ngw == 1) v4_body<RPL, TRI, CFULL, (NG > 1 ? 1 : 0), NCT, RMASK, Post, GATHER, NAP>(c, w, stage, W2l, vmask, smask, post, coff);
+    else v4_body<RPL, TRI, CFULL, 0, NCT, RMASK, Post, GATHER, NAP>(c, w, stage, W2l, vmask, smask, post, coff);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The carried right-hand side d = Q'(-J1 p1 - rx) is the LAST trailing column of every panel, so the trailing column count is
 // always 32 j + 1: in the block kernel above that one column cost a whole 16-column block per tile and panel — 13 % of the
-// level-0 workgroups of a C2 solve, each reading 15 spare columns from HBM for nothing.  This kernel applies the tile's block
-// reflector to that single column instead: d -= V (T' (V' d)) with the tile's V read ONCE (row pairs, 16-byte full-line loads,
-// kept in registers), the 32 dot products reduced with the batched wave reductions, T' applied by one wave.
+// level-0 workgroups of a C2 solve, each reading 15 spare columns from HBM for nothing.  This routine applies the tile's block
+// reflector(s) to that single column instead: d -= V (T' (V' d)) with the tile's V read ONCE (row pairs, 16-byte full-line loads,
+// kept in registers), the 32 dot products reduced with the batched wave reductions, T' applied by one wave; for a panel pair the
+// second panel's reflector follows while d stays in registers.
 // Runs as the LAST block index (blockIdx.y) of the block kernel's own grid, so that the tile's V is read while the column blocks of
 // the same tile keep it hot in the XCD's L2 (as a launch of its own, after the block kernel, it re-read 400 MB of reflectors per
 // panel from HBM and gave the gain back).  256 threads: thread = row pair of a 512-row tile (RPL = 8); RPL = 4 uses 128 of them.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int RPL>
+template <int RPL, bool PAIR>
 __device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB], double* w2s) {
     constexpr int NWV = 4;                                               // waves of the block kernel's workgroup
     const int prob = blockIdx.z + a.prob0;
     const ProbState st = a.state[prob];
-    const int r0 = a.panel * PB;
-    if (r0 >= st.kp) return;
-    const int bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
-    if (st.n2 + 1 - (r0 + bw) < 1) return;
-    const int col0 = st.rankA + r0;
+    const int r0a = a.panel * PB;
+    if (r0a >= st.kp) return;
     const int g = blockIdx.x;
     const double* Wm = a.W + prob * a.sW;
     double* dcol = a.W + prob * a.sW + (size_t)a.n * a.ldw;
-    const double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
-    const long long tile_row0 = (long long)r0 + (long long)g * a.F * 32;
+    const long long tile_row0 = a.base + (long long)g * a.F * 32;
     const long long blocks_here = (long long)a.nblocks - (long long)g * a.F;
     const int nvu = (int)(blocks_here < a.F ? blocks_here : a.F);        // valid 32-row units of this tile
     const int tid = threadIdx.x, ln = lane_id(), w = wave_id();
     const int s0 = 2 * tid;                                              // first slot of the thread's row pair
     const bool live = (s0 < 64 * RPL) && (s0 >> 5) < nvu;
-    // V row pairs (structure of the tile's first 32 rows: unit lower trapezoid; columns >= bw do not exist), d row pair
-    v4_d2 v[PB];
     v4_d2 dd = (v4_d2){0.0, 0.0};
-    const double* vrow = Wm + (size_t)col0 * a.ldw + tile_row0 + s0;
-    if (live) {
+    if (live) dd = *(const v4_d2*)(dcol + tile_row0 + s0);
+    const bool has_next = caqr_next_bw(st.kp, r0a) > 0;                  // uniform over the workgroup
+    if (PAIR && !has_next) return;                                       // served by the plain kernel (a.pair == 2)
+    if (!PAIR && a.pair == 2 && has_next) return;
+    constexpr int napp = PAIR ? 2 : 1;
 #pragma unroll
-        for (int j = 0; j < PB; ++j) v[j] = *(const v4_d2*)(vrow + (size_t)j * a.ldw);
-        dd = *(const v4_d2*)(dcol + tile_row0 + s0);
-    }
+    for (int ai = 0; ai < napp; ++ai) {
+        const int r0 = r0a + PB * ai;
+        const int bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
+        const int col0 = st.rankA + r0;
+        const int dsh = 32 * (a.skip + ai);                              // slot of reflector j's diagonal = j + dsh
+        const double* T = a.Tbuf + prob * a.sT + ((ai ? a.tOff2 : a.tOff) + g) * (long long)(PB * PB);
+        // V row pairs (structure of the tile's first rows: zero above the diagonal, one on it; columns >= bw do not exist)
+        v4_d2 v[PB];
+        const double* vrow = Wm + (size_t)col0 * a.ldw + tile_row0 + s0;
+        if (live) {
 #pragma unroll
-    for (int j = 0; j < PB; ++j) {
+            for (int j = 0; j < PB; ++j) v[j] = *(const v4_d2*)(vrow + (size_t)j * a.ldw);
+        }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int s = s0 + p;
-            double x = live ? v[j][p] : 0.0;
-            if (s0 < PB) x = (s > j) ? x : ((s == j) ? 1.0 : 0.0);
-            v[j][p] = (j < bw && live) ? x : 0.0;
+        for (int j = 0; j < PB; ++j) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int s = s0 + p;
+                double x = live ? v[j][p] : 0.0;
+                if (s0 < PB + dsh) x = (s > j + dsh) ? x : ((s == j + dsh) ? 1.0 : 0.0);
+                v[j][p] = (j < bw && live) ? x : 0.0;
+            }
+        }
+        // w1 = V' d: per-thread partial products, batched wave reductions, partials of the waves through LDS
+#pragma unroll
+        for (int j8 = 0; j8 < PB; j8 += 8) {
+            double pr[8], rs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pr[u] = v[j8 + u][0] * dd[0] + v[j8 + u][1] * dd[1];
+            wave_allsum8(pr, rs);
+            if (ln == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) part[w][j8 + u] = rs[u];
+            }
+        }
+        __syncthreads();
+        // w2 = -T' w1 (T upper triangular, column-major): lane k of wave 0
+        if (w == 0 && ln < PB) {
+            double acc = 0.0;
+            for (int l = 0; l <= ln; ++l) {
+                double w1 = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < NWV; ++ww) w1 += part[ww][l];
+                acc += T[l + ln * PB] * w1;
+            }
+            w2s[ln] = (ln < bw) ? -acc : 0.0;
+        }
+        __syncthreads();
+        if (live) {
+            double d0 = dd[0], d1 = dd[1];
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                const double wk = w2s[k];
+                d0 += v[k][0] * wk;
+                d1 += v[k][1] * wk;
+            }
+            dd = (v4_d2){d0, d1};
         }
     }
-    // w1 = V' d: per-thread partial products, batched wave reductions, partials of the waves through LDS
-#pragma unroll
-    for (int j8 = 0; j8 < PB; j8 += 8) {
-        double pr[8], rs[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pr[u] = v[j8 + u][0] * dd[0] + v[j8 + u][1] * dd[1];
-        wave_allsum8(pr, rs);
-        if (ln == 0) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) part[w][j8 + u] = rs[u];
-        }
-    }
-    __syncthreads();
-    // w2 = -T' w1 (T upper triangular, column-major): lane k of wave 0
-    if (w == 0 && ln < PB) {
-        double acc = 0.0;
-        for (int l = 0; l <= ln; ++l) {
-            double w1 = 0.0;
-#pragma unroll
-            for (int ww = 0; ww < NWV; ++ww) w1 += part[ww][l];
-            acc += T[l + ln * PB] * w1;
-        }
-        w2s[ln] = (ln < bw) ? -acc : 0.0;
-    }
-    __syncthreads();
-    if (live) {
-        double d0 = dd[0], d1 = dd[1];
-#pragma unroll
-        for (int k = 0; k < PB; ++k) {
-            const double wk = w2s[k];
-            d0 += v[k][0] * wk;
-            d1 += v[k][1] * wk;
-        }
-        *(v4_d2*)(dcol + tile_row0 + s0) = (v4_d2){d0, d1};
-    }
+    if (live) *(v4_d2*)(dcol + tile_row0 + s0) = dd;
 }
 
 #ifndef ENLSIP_V4_CW
 #define ENLSIP_V4_CW 32          // columns per workgroup (experiment: 16 with 3 workgroups per CU)
 #endif
+
+// Context of one workgroup of the block kernels below.  Returns false when the workgroup has nothing to do.
+// PAIR: the far update of a panel pair (both level-0 reflectors in one pass): only problems that HAVE the pair's second panel;
+// the plain kernel with a.pair == 2 serves the others (mixed-rank batches in the second attempt of a solve).
+template <bool TRI, bool PAIR>
+__device__ __forceinline__ bool v4_setup(const CaqrArgs& a, V4Ctx& c, int& nvu, int& ncols) {
+    const int prob = blockIdx.z + a.prob0;
+    const ProbState st = a.state[prob];
+    const int r0 = a.panel * PB;
+    if (r0 >= st.kp) return false;
+    c.bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
+    c.col0 = st.rankA + r0;
+    const int g = blockIdx.x;
+    // column window (pairs): the next panel's columns only / everything beyond them
+    const int bwn = (a.win || a.pair) ? caqr_next_bw(st.kp, r0) : 0;
+    if (PAIR && bwn == 0) return false;
+    if (!PAIR && a.pair == 2 && bwn > 0) return false;
+    int first = r0 + c.bw;
+    ncols = st.n2 + 1 - first - ((!TRI && a.skip_rhs) ? 1 : 0);
+    if (a.win == 1) ncols = bwn;
+    else if (a.win == 2) { first += bwn; ncols -= bwn; }
+    c.cb0 = blockIdx.y * ENLSIP_V4_CW;
+    if (c.cb0 >= ncols) return false;
+    c.rows_valid = 0;
+    c.dshift = 32 * a.skip;
+    c.mode = a.mode;
+    c.Wm = a.W + prob * a.sW;
+    c.C = a.W + prob * a.sW + (size_t)(st.rankA + first) * a.ldw;
+    c.T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
+    c.gblk0 = (long long)g * a.F;
+    c.r0 = a.base;
+    c.S = a.S;
+    c.ldw = a.ldw;
+    c.tile_row0 = a.base + c.gblk0 * 32;
+    c.T2 = a.Tbuf + prob * a.sT + (a.tOff2 + g) * (long long)(PB * PB);
+    c.col02 = c.col0 + PB;
+    c.bw2 = bwn;
+    c.dshift2 = c.dshift + 32;
+    const long long blocks_here = (long long)a.nblocks - (long long)g * a.F;
+    nvu = (int)(blocks_here < a.F ? blocks_here : a.F);                  // valid 32-row units of this group
+    return true;
+}
+__device__ __forceinline__ unsigned v4_colmask(int cb0, int ncols) {     // valid (= stored) columns of this lane
+    unsigned cmask = 0u;
+    const int lq = lane_id() >> 4;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) cmask |= (cb0 + 16 * (b >> 2) + 4 * (b & 3) + lq < ncols) ? (1u << b) : 0u;
+    return cmask;
+}
+
 template <int RPL, bool TRI>
 __global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update_v4(CaqrArgs a) {
     __shared__ __attribute__((aligned(16))) double stage[4][V4_STAGE];   // per-wave transpose images / W1 partials
@@ -431,42 +543,16 @@ __global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update
 
     V4_STAMP(6);
     if (!TRI && a.skip_rhs && blockIdx.y == gridDim.y - 1) {             // the carried right-hand side of this tile
-        v4_rhs_body<RPL>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l);
+        v4_rhs_body<RPL, false>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l);
         return;
     }
-    const int prob = blockIdx.z + a.prob0;
-    const ProbState st = a.state[prob];
-    const int r0 = a.panel * PB;
-    if (r0 >= st.kp) return;
     V4Ctx c;
-    c.bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
-    c.col0 = st.rankA + r0;
-    const int g = blockIdx.x;
-    const int first = r0 + c.bw;
-    const int ncols = st.n2 + 1 - first - ((!TRI && a.skip_rhs) ? 1 : 0);
-    c.cb0 = blockIdx.y * ENLSIP_V4_CW;
-    if (c.cb0 >= ncols) return;
-    c.rows_valid = 0;
-    c.dshift = 0;
-    c.Wm = a.W + prob * a.sW;
-    c.C = a.W + prob * a.sW + (size_t)(st.rankA + first) * a.ldw;
-    c.T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
-    c.gblk0 = (long long)g * a.F;
-    c.r0 = r0;
-    c.S = a.S;
-    c.ldw = a.ldw;
-    c.tile_row0 = (long long)r0 + c.gblk0 * 32;
-    const long long blocks_here = (long long)a.nblocks - (long long)g * a.F;
-    const int nvu = (int)(blocks_here < a.F ? blocks_here : a.F);        // valid 32-row units of this group
+    int nvu, ncols;
+    if (!v4_setup<TRI, false>(a, c, nvu, ncols)) return;
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
     const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;                     // units w, w + 4, ... < nvu
     const bool cfull = (ncols - c.cb0 >= 32) && (c.bw == PB);
-    unsigned cmask = 0u;       // valid (= stored) columns of this lane
-    {
-        const int lq = lane_id() >> 4;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) cmask |= (c.cb0 + 16 * (b >> 2) + 4 * (b & 3) + lq < ncols) ? (1u << b) : 0u;
-    }
+    const unsigned cmask = v4_colmask(c.cb0, ncols);
     if (ENLSIP_V4_CW == 16) {
         if ((ncols - c.cb0 >= 16) && (c.bw == PB)) v4_dispatch<RPL, TRI, true, 1>(c, w, ngw, stage, W2l);
         else v4_dispatch<RPL, TRI, false, 1>(c, w, ngw, stage, W2l, cmask, cmask);
@@ -475,10 +561,36 @@ __global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update
     else v4_dispatch<RPL, TRI, false, 2>(c, w, ngw, stage, W2l, cmask, cmask);
 }
 
+// Far update of a panel pair: level-0 reflectors of panel a.panel AND of a.panel + 1 applied to every column beyond the pair
+// in ONE pass (the block of C stays in registers between the two): half the HBM traffic of two passes.
+template <int RPL>
+__global__ __launch_bounds__(256, 2) void k_caqr_update_v4_pair(CaqrArgs a) {
+    __shared__ __attribute__((aligned(16))) double stage[4][V4_STAGE];
+    __shared__ __attribute__((aligned(16))) double W2l[PB * PB];
+
+    if (a.skip_rhs && blockIdx.y == gridDim.y - 1) {
+        v4_rhs_body<RPL, true>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l);
+        return;
+    }
+    V4Ctx c;
+    int nvu, ncols;
+    if (!v4_setup<false, true>(a, c, nvu, ncols)) return;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;
+    const bool cfull = (ncols - c.cb0 >= 32) && (c.bw == PB) && (c.bw2 == PB);
+    const unsigned cmask = v4_colmask(c.cb0, ncols);
+    if (cfull) v4_dispatch<RPL, false, true, 2, false, V4NoPost, false, 2>(c, w, ngw, stage, W2l);
+    else if (ncols - c.cb0 <= 16) v4_dispatch<RPL, false, false, 1, false, V4NoPost, false, 2>(c, w, ngw, stage, W2l, cmask, cmask);
+    else v4_dispatch<RPL, false, false, 2, false, V4NoPost, false, 2>(c, w, ngw, stage, W2l, cmask, cmask);
+}
+
 inline void launch_update_v4(int RPL, const CaqrArgs& a, int groups, int ncols, int batch, hipStream_t s) {
     // level 0 with skip_rhs: ncols counts the J2 columns only; one more block index carries the right-hand side
     dim3 grid(groups, (ncols + ENLSIP_V4_CW - 1) / ENLSIP_V4_CW + ((a.level == 0 && a.skip_rhs) ? 1 : 0), batch);
-    if (a.level == 0) {
+    if (a.level == 0 && a.pair == 1) {
+        if (RPL == 8) hipLaunchKernelGGL((k_caqr_update_v4_pair<8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_caqr_update_v4_pair<4>), grid, dim3(256), 0, s, a);
+    } else if (a.level == 0) {
         if (RPL == 8) hipLaunchKernelGGL((k_caqr_update_v4<8, false>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_caqr_update_v4<4, false>), grid, dim3(256), 0, s, a);
     } else {

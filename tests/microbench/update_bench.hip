@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
     CaqrArgs a{};
     a.m = m; a.n = n; a.ldw = ldw; a.panel = panel; a.level = level; a.F = F; a.nblocks = nblocks; a.S = S; a.tOff = 0;
     a.W = dW; a.sW = sW; a.Tbuf = dT; a.sT = sT; a.state = dS; a.prob0 = 0;
+    a.mode = level == 0 ? 0 : 1; a.base = 32 * panel; a.skip = 0; a.win = 0; a.pair = 0; a.tOff2 = 0;
 
     // ---- host check of problem 0: C - V (T' (V' C)) in plain loops on sampled columns ---------------------
     {
@@ -102,6 +103,73 @@ int main(int argc, char** argv) {
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (level == 0) {
+        // ---- panel pair (panel, panel + 1): far columns get both level-0 reflectors in one pass; checked against two host passes ----
+        CaqrArgs ap = a;
+        ap.pair = 1; ap.win = 2; ap.tOff2 = 16;          // T blocks of the second panel: 16 .. 16 + groups - 1
+        const int nfar = ntrail - 32;
+        ap.skip_rhs = ((nfar - 1) % 32 == 0) ? 1 : 0;
+        launch_update_v4(RPL, ap, groups, ntrail - ap.skip_rhs, 1, 0);
+        CK(hipDeviceSynchronize());
+        std::vector<double> r1((size_t)sW);
+        CK(hipMemcpy(r1.data(), dW, r1.size() * 8, hipMemcpyDeviceToHost));
+        const int r0 = 32 * panel, col0 = t + r0, first = r0 + 64;
+        double maxd = 0, maxc = 0;
+        for (int g = 0; g < groups; ++g) {
+            const int nb = std::min(F, nblocks - g * F);
+            const int rows = nb * 32;
+            auto rowof = [&](int s) { return (long long)r0 + (long long)g * F * 32 + s; };
+            std::vector<double> x(rows);
+            for (int cc = 0; cc < nfar; cc += std::max(1, nfar / 9)) {
+                const int ccol = (cc == 0) ? nfar - 1 : cc;       // include the carried right-hand side (last column)
+                const size_t co = (size_t)(t + first + ccol) * ldw;
+                for (int s = 0; s < rows; ++s) x[s] = hW[rowof(s) + co];
+                for (int ai = 0; ai < 2; ++ai) {
+                    const int dsh = 32 * ai;
+                    double w1[32], w2[32];
+                    auto V = [&](int s, int j) { return s > j + dsh ? hW[rowof(s) + (size_t)(col0 + 32 * ai + j) * ldw] : (s == j + dsh ? 1.0 : 0.0); };
+                    for (int j = 0; j < 32; ++j) { w1[j] = 0; for (int s = 0; s < rows; ++s) w1[j] += V(s, j) * x[s]; }
+                    for (int k = 0; k < 32; ++k) { w2[k] = 0; for (int l = 0; l <= k; ++l) w2[k] += hT[(size_t)(g + 16 * ai) * 1024 + l + k * 32] * w1[l]; }
+                    for (int s = 0; s < rows; ++s) for (int k = 0; k < 32; ++k) x[s] -= V(s, k) * w2[k];
+                }
+                for (int s = 0; s < rows; ++s) {
+                    maxd = fmax(maxd, fabs(x[s] - r1[rowof(s) + co]));
+                    maxc = fmax(maxc, fabs(x[s] - hW[rowof(s) + co]));
+                }
+            }
+        }
+        // the pair's own 32 + 32 columns and everything left of them must be untouched
+        double maxu = 0;
+        for (size_t e = 0; e < (size_t)(t + first) * ldw; ++e) maxu = fmax(maxu, fabs(r1[e] - hW[e]));
+        printf("PAIR host check (problem 0, sampled far columns + rhs): max |kernel - two host passes| = %.3e (change %.3e); untouched part differs by %.3e\n", maxd, maxc, maxu);
+        CK(hipMemcpy(dW, hW.data(), (size_t)sW * 8, hipMemcpyHostToDevice));
+        // timing: two plain passes (panel, then panel + 1 on its own trailing columns) against narrow + pair
+        CaqrArgs a1 = a; a1.skip_rhs = ((ntrail - 1) % 32 == 0);
+        CaqrArgs a2 = a; a2.panel = panel + 1; a2.base = 32 * (panel + 1); a2.nblocks = nblocks - 1; a2.tOff = 16; a2.skip_rhs = ((nfar - 1) % 32 == 0);
+        const int g2 = (nblocks - 1 + F - 1) / F;
+        CaqrArgs an = a; an.win = 1;
+        auto timeit = [&](const char* name, auto&& go, double bytes_) {
+            for (int i = 0; i < 2; ++i) go();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 5; ++i) go();
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+            printf("%-34s %.3f ms   %.0f GB/s algorithmic (SURVEY 8d bytes)\n", name, ms, bytes_ / ms * 1e-6);
+            return ms;
+        };
+        const double rk = (double)nblocks * 32;
+        const double b1 = (double)batch * 8.0 * (2.0 * rk * ntrail + rk * 32), b2 = (double)batch * 8.0 * (2.0 * (rk - 32) * nfar + (rk - 32) * 32);
+        const double bn = (double)batch * 8.0 * (2.0 * rk * 32 + rk * 32), bf = (double)batch * 8.0 * (2.0 * rk * nfar + rk * 32) + b2;
+        for (int rep = 0; rep < 2; ++rep) {
+            const float t1 = timeit("plain pass, first panel", [&] { launch_update_v4(RPL, a1, groups, ntrail - a1.skip_rhs, batch, 0); }, b1);
+            const float t2 = timeit("plain pass, second panel", [&] { launch_update_v4(RPL, a2, g2, nfar - a2.skip_rhs, batch, 0); }, b2);
+            const float t3 = timeit("narrow (second panel's columns)", [&] { launch_update_v4(RPL, an, groups, 32, batch, 0); }, bn);
+            const float t4 = timeit("pair, far columns", [&] { launch_update_v4(RPL, ap, groups, ntrail - ap.skip_rhs, batch, 0); }, bf);
+            printf("  two plain passes %.3f ms   narrow + pair %.3f ms   ratio %.3f\n", t1 + t2, t3 + t4, (t3 + t4) / (t1 + t2));
+        }
+    }
     const int reps = 5;
     const double rows_k = (double)nblocks * 32;
     const double bytes = (double)batch * 8.0 * (2.0 * rows_k * ntrail + rows_k * 32);

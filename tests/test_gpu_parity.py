@@ -565,12 +565,17 @@ def test_linearity_in_rhs(solver):
 
 
 @pytest.mark.parametrize("m,n,t,G", [(4000, 64, 0, 4), (3001, 48, 5, 3), (20000, 96, 0, 8), (300, 40, 6, 2),
-                                     (6000, 300, 10, 3), (5000, 600, 4, 2)])     # combine stage: register blocks / > 512 rows
+                                     (6000, 300, 10, 3), (5000, 600, 4, 2),      # combine stage: register blocks / > 512 rows
+                                     (8800, 1008, 0, 8), (16384, 144, 16, 8)])    # stacks whose tiles are rotated out EXACTLY (below)
 def test_tsqr_row_shards_match_single_solve(m, n, t, G, solver):
     """Row-sharded TSQR (config C4 structure) rehearsed on one GPU: G local stages + combine must
-    reproduce the oracle's p, ranks, pivots and ||d|| of the unsharded problem."""
+    reproduce the oracle's p, ranks, pivots and ||d|| of the unsharded problem.
+    (8800, 1008, 0, 8): the combine stage factors a stack of eight 1008-row triangles; with panel pairs a tile of the stack holds
+    nothing but the first 32 rows of the next triangle, the first panel rotates them out exactly, and the second panel of the pair
+    meets columns of rounding dust whose norms fall by 1e-16 per column down to 1e-159 — reflectors built from underflowing sums
+    of squares were not orthogonal (p off by 1e-10); make_reflector now treats columns below 1e-140 as zero."""
     from enlsip_gn.tsqr import tsqr_solve_shards
-    J, rx, A, cx = synth.make_problem(900 + m, m, n, t)
+    J, rx, A, cx = synth.make_problem(11 if m == 8800 else 900 + m, m, n, t)
     ref = go.gn_subproblem(J, rx, A, cx)
     res = tsqr_solve_shards(solver, J, rx, A, cx, G)
     assert res.n2 == n - ref.rankA and res.rankA == ref.rankA and res.rankJ2 == ref.rankJ2
