@@ -770,10 +770,12 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         GN_HIP(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); h->stage_ms[ENLSIP_GN_STAGE_JQ1] = ms;
         GN_HIP(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
         float upd = 0.f;
+        h->upd_launch_ms.clear();
         for (size_t i = 0; i + 1 < h->upd_used; i += 2) {
             float u;
             GN_HIP(hipEventElapsedTime(&u, h->upd_ev[i], h->upd_ev[i + 1]));
             upd += u;
+            h->upd_launch_ms.push_back(u);
         }
         h->upd_launches = (long long)(h->upd_used / 2);
         h->upd_avg_ms = h->upd_launches ? upd / (float)h->upd_launches : 0.f;
@@ -916,6 +918,61 @@ int enlsip_gn_get_stage_ms(enlsip_gn_handle h, float* ms) {
     if (!ms) return -2;
     for (int i = 0; i < ENLSIP_GN_STAGE_COUNT; ++i) ms[i] = h->stage_ms[i];
     return 0;
+}
+
+int enlsip_gn_get_update_table(enlsip_gn_handle h, int64_t cap, double* algorithmic_bytes, float* ms, int64_t* count) {
+    if (!h) return -1;
+    const size_t nl = std::min(h->upd_launch_ms.size(), h->upd_launch_bytes.size());
+    if (count) *count = (int64_t)nl;
+    for (size_t i = 0; i < nl && (int64_t)i < cap; ++i) {
+        if (algorithmic_bytes) algorithmic_bytes[i] = h->upd_launch_bytes[i];
+        if (ms) ms[i] = h->upd_launch_ms[i];
+    }
+    return 0;
+}
+
+// In-place read-modify-write stream over `bytes` of scratch memory with the trailing update's access shape (256-thread
+// workgroups, 16-byte non-temporal loads and stores, 256 contiguous bytes per 16 lanes): the ceiling an in-place update of
+// streamed data can reach on THIS device, measured with HIP events on the handle's stream.
+__global__ __launch_bounds__(256) void k_stream_inplace(double* buf, long long n2pairs) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* p = (d2*)buf;
+    // one workgroup = 32 KB chunks of 256 x 16 B, eight of them (the update's 128 KB block of C per workgroup would be sixteen)
+    const long long chunk = 256;
+    for (long long c = (long long)blockIdx.x * 8; c < (long long)blockIdx.x * 8 + 8; ++c) {
+        const long long i = c * chunk + threadIdx.x;
+        if (i < n2pairs) {
+            d2 x = __builtin_nontemporal_load(p + i);
+            x[0] += 1.0; x[1] -= 1.0;
+            __builtin_nontemporal_store(x, p + i);
+        }
+    }
+}
+int enlsip_gn_measure_stream(enlsip_gn_handle h, int64_t bytes, int reps, double* gbytes_per_s) {
+    if (!h) return -1;
+    GN_TRY
+    if (bytes < (1 << 20) || reps < 1 || !gbytes_per_s) { h->err = "measure_stream: bytes >= 1 MiB, reps >= 1, non-NULL result"; return -2; }
+    GN_HIP(hipSetDevice(h->device));
+    int rc = grow(h, h->scratch, (size_t)bytes);
+    if (rc) return rc;
+    const long long pairs = bytes / 16;
+    const unsigned grid = (unsigned)((pairs + 256 * 8 - 1) / (256 * 8));
+    hipEvent_t e0, e1;
+    GN_HIP(hipEventCreate(&e0));
+    GN_HIP(hipEventCreate(&e1));
+    GN_HIP(hipMemsetAsync(h->scratch.p, 0, (size_t)bytes, h->stream));
+    hipLaunchKernelGGL(k_stream_inplace, dim3(grid), dim3(256), 0, h->stream, (double*)h->scratch.p, pairs);
+    GN_HIP(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_stream_inplace, dim3(grid), dim3(256), 0, h->stream, (double*)h->scratch.p, pairs);
+    GN_HIP(hipEventRecord(e1, h->stream));
+    GN_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GN_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbytes_per_s = 2.0 * (double)(pairs * 16) * reps / ((double)ms * 1e-3) / 1e9;
+    return 0;
+    GN_CATCH(h)
 }
 
 // debugging aid (not part of include/enlsip_gn.h): the working matrix W (ldw x (n + 1)) of problem `prob` as it stands

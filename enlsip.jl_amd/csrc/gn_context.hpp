@@ -106,6 +106,8 @@ struct enlsip_gn_context {
     enlsip_gn_allgather_fn tsqr_xfn = nullptr;
     void* tsqr_xctx = nullptr;
     int tsqr_ranks = 1, tsqr_rank = 0;
+    bool tsqr_broken = false;           // enlsip_gn_tsqr_init_rccl failed: enlsip_gn_solve_tsqr refuses until a communicator is set again
+    int tsqr_transport = 0;             // what moved the triangles in the last enlsip_gn_solve_tsqr (ENLSIP_GN_TRANSPORT_*)
     gn::DevBuf xbuf;                    // send message + G received messages
     float tsqr_ms[3] = {};              // local / exchange / combine of the last enlsip_gn_solve_tsqr (profiling on)
     long long *jpvtA = nullptr, *jpvtL = nullptr, *jpvtJ = nullptr;
@@ -129,6 +131,7 @@ struct enlsip_gn_context {
     size_t upd_used = 0;
     double upd_bytes = 0.0;
     std::vector<double> upd_launch_bytes;   // per timed launch, same order as the event pairs
+    std::vector<float> upd_launch_ms;
     float upd_avg_ms = 0.f;
     long long upd_launches = 0;
 };

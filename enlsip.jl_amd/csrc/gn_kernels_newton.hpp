@@ -124,4 +124,11 @@ __global__ __launch_bounds__(256) void k_newton_solve(int n2, const double* L, l
     if (threadIdx.x == 0 && st) flag[1] = st;
 }
 
+// Ep = E[p, p] (1-based permutation p of 1..n): newton_search_direction :396-399
+__global__ void k_newton_perm(int n, const double* E, const long long* p, double* Ep) {
+    const int j = blockIdx.x;
+    const long long cj = p[j] - 1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) Ep[i + (size_t)j * n] = E[(p[i] - 1) + (size_t)cj * n];
+}
+
 }  // namespace gn

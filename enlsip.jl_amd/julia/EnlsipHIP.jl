@@ -169,11 +169,27 @@ function gn_search_direction_hip!(h::Handle, J::Matrix{Float64}, rx::Vector{Floa
 end
 
 """
+    d_gn_prefix(d_gn, k, n, rankA) -> view(d_gn, 1:k)
+
+The leading `n - rankA` entries of `d_gn` agree with the reference's up to a sign per entry (the thin Q of `F_J2` is unique up
+to column signs once the pivots are fixed), so every norm of a prefix `d_gn[1:k]` with `k <= n - rankA` is the reference's; the
+entries beyond are an orthogonal transform of the reference's tail and only their norm as a whole is the same (SURVEY §7 H1).
+The reference slices such prefixes in `search_direction_analys` (`d_gn[1:prev_dimJ2m1]`, src/enlsip_functions.jl:1230-1231),
+`choose_subspace_dimensions` (:1166-1169) and `check_termination_criteria` (:2448-2452); with `dimJ2 <= n - t_prev` they never
+reach past `n - rankA`.  Route those slices through this helper when the HIP backend is active: it asserts the bound instead
+of silently mixing tail components into a norm.
+"""
+function d_gn_prefix(d_gn::AbstractVector{Float64}, k::Integer, n::Integer, rankA::Integer)
+    @assert 0 <= k <= n - rankA "d_gn[1:$k] reaches past n - rankA = $(n - rankA): only the norm of the whole tail is defined there (src/enlsip_functions.jl:1230-1231)"
+    return view(d_gn, 1:k)
+end
+
+"""
     sub_search_direction_hip(h, m, n, t, dimA, dimJ2, code) -> p, b, d
 
 Re-entry of `sub_search_direction` on the resident factors with truncated dimensions
 (src/enlsip_functions.jl:1253, subspace minimisation).  SURVEY §7 H1: callers that slice
-`d_gn[1:k]` must keep `k <= n - rankA`; assert that in the caller.
+`d_gn[1:k]` must keep `k <= n - rankA`: `d_gn_prefix` above asserts it.
 """
 function sub_search_direction_hip(h::Handle, m::Integer, n::Integer, t::Integer, dimA::Integer, dimJ2::Integer, code::Integer)
     p = zeros(Float64, n); b = zeros(Float64, t); d = zeros(Float64, m)

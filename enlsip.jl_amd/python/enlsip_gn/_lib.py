@@ -83,9 +83,12 @@ PROTOTYPES = {
     "enlsip_gn_solve_tsqr": (C.c_int, [_h, _i64, _i64, _i64, C.c_void_p, _i64, C.c_void_p, C.c_void_p, _i64, C.c_void_p,
                                        C.c_double, C.c_void_p, C.c_void_p, _dp, C.POINTER(Info), C.c_void_p]),
     "enlsip_gn_tsqr_get_stage_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
+    "enlsip_gn_tsqr_get_transport": (C.c_int, [_h, C.POINTER(C.c_int)]),
     "enlsip_gn_set_profiling": (C.c_int, [_h, C.c_int]),
     "enlsip_gn_get_stage_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "enlsip_gn_get_update_stats": (C.c_int, [_h, C.POINTER(C.c_float), _ip, _dp]),
+    "enlsip_gn_get_update_table": (C.c_int, [_h, C.c_int64, _dp, C.POINTER(C.c_float), _ip]),
+    "enlsip_gn_measure_stream": (C.c_int, [_h, C.c_int64, C.c_int, _dp]),
 }
 
 _lib = None

@@ -276,5 +276,20 @@ class GNSolver:
         self._chk(self._lib.enlsip_gn_get_update_stats(self._h, C.byref(ms), C.byref(cnt), C.byref(by)))
         return float(ms.value), int(cnt.value), float(by.value)
 
+    def update_table(self):
+        """Per timed level-0 far-update launch of the last profiled solve: [(SURVEY 8d bytes, ms), ...] in sweep order."""
+        cap = 256
+        by = (C.c_double * cap)()
+        ms = (C.c_float * cap)()
+        cnt = C.c_int64(0)
+        self._chk(self._lib.enlsip_gn_get_update_table(self._h, cap, by, ms, C.byref(cnt)))
+        return [(float(by[i]), float(ms[i])) for i in range(min(int(cnt.value), cap))]
+
+    def measure_stream(self, nbytes: int = 1 << 30, reps: int = 5) -> float:
+        """GB/s of an in-place non-temporal read-modify-write stream with the trailing update's access shape on this device."""
+        out = C.c_double(0.0)
+        self._chk(self._lib.enlsip_gn_measure_stream(self._h, nbytes, reps, C.byref(out)))
+        return float(out.value)
+
     def synchronize(self):
         self._chk(self._lib.enlsip_gn_synchronize(self._h))

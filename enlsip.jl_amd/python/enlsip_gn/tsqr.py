@@ -133,18 +133,21 @@ def tsqr_attach(solver: GNSolver, group=None, transport: str = "rccl"):
     G = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lib, h = solver._lib, solver._h
-    if G == 1:
+    if G == 1 and transport != "rccl":
         solver._chk(lib.enlsip_gn_tsqr_set_exchange(h, None, None, 1, 0))
         return
     if transport == "rccl":
+        # also with ONE rank: the library then runs its exchange as a self-gather through RCCL (transport "rccl" in
+        # tsqr_transport), so the RCCL leg is exercised on a one-GPU box
         ident = C.create_string_buffer(128)
         if rank == 0:
             rc = lib.enlsip_gn_tsqr_unique_id(ident)
             if rc != 0:
                 raise RuntimeError(f"enlsip_gn_tsqr_unique_id failed with code {rc} (RCCL not loadable?)")
-        box = [ident.raw if rank == 0 else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident = C.create_string_buffer(box[0], 128)
+        if G > 1:
+            box = [ident.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
         solver._chk(lib.enlsip_gn_tsqr_init_rccl(h, ident, G, rank))
         return
     if transport != "host":
@@ -185,6 +188,16 @@ def tsqr_solve_lib(solver: GNSolver, J_loc, rx_loc, At, cx, eps_rank: float = SQ
     n2 = n - int(info.rankA)
     return TSQRResult(p=p, dlead=dlead[:n2].copy(), d_norm=float(dn.value), rankA=int(info.rankA), rankJ2=int(info.rankJ2),
                       code=int(info.code), jpvtJ2=jp[:n2].copy(), n2=n2)
+
+
+TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "callback"}
+
+
+def tsqr_transport(solver: GNSolver) -> str:
+    """What moved the messages in the handle's last ``enlsip_gn_solve_tsqr``: "none" (one rank, device copy), "rccl", "callback"."""
+    code = C.c_int(-1)
+    solver._chk(solver._lib.enlsip_gn_tsqr_get_transport(solver._h, C.byref(code)))
+    return TRANSPORT_NAMES.get(int(code.value), str(code.value))
 
 
 def tsqr_stage_ms(solver: GNSolver):

@@ -255,7 +255,11 @@ int enlsip_gn_tsqr_combine_dev(enlsip_gn_handle h, int64_t G, int64_t n2,
  *
  * enlsip_gn_solve_tsqr: rank g passes its m_loc rows of J and rx (device pointers; the row blocks may have different heights)
  * and the replicated At, cx.  One message per rank travels: the packed upper triangle of the local R (8 n2 (n2 + 1) / 2 bytes:
- * 4.2 MB at n2 = 1024), z = (Q_loc' d_loc)[1:n2] and the squared norm of the local tail.  Every rank returns the same HOST
+ * 4.2 MB at n2 = 1024), z = (Q_loc' d_loc)[1:n2], the squared norm of the local tail and the sender's n2; its length depends on n
+ * alone, so the ranks' counts agree even if their n2 do not — that case (the ranks see different constraint ranks) returns -13.
+ * A rank that fails BEFORE the exchange (bad arguments, out of memory, a HIP error in its local stage) leaves its peers waiting
+ * in the all-gather: such a failure is fatal for the communicator.  After a failed enlsip_gn_tsqr_init_rccl the handle has no
+ * communicator and enlsip_gn_solve_tsqr returns an error until one is set again.  Every rank returns the same HOST
  * outputs: p (n), dlead (n2 <= n entries: leading entries of F_J2.Q' d), d_norm = ||d||_2 over all ranks, info, jpvtJ2 (n2 <= n).
  */
 int enlsip_gn_tsqr_unique_id(void* id128);
@@ -268,6 +272,14 @@ int enlsip_gn_solve_tsqr(enlsip_gn_handle h, int64_t m_loc, int64_t n, int64_t t
                          double* p, double* dlead, double* d_norm, enlsip_gn_info* info, int64_t* jpvtJ2);
 /* local / exchange / combine time (ms, HIP events) of the last enlsip_gn_solve_tsqr with profiling enabled */
 int enlsip_gn_tsqr_get_stage_ms(enlsip_gn_handle h, float* ms3);
+/* what moved the messages in the last enlsip_gn_solve_tsqr of this handle: an attached RCCL communicator is used for the
+ * exchange even when it has ONE rank (a self-gather), so that the RCCL leg runs on a one-GPU box too */
+enum {
+    ENLSIP_GN_TRANSPORT_NONE = 0,     /* one rank, no communicator: a device copy */
+    ENLSIP_GN_TRANSPORT_RCCL = 1,     /* ncclAllGather on the handle's stream */
+    ENLSIP_GN_TRANSPORT_CALLBACK = 2  /* the caller's all-gather (enlsip_gn_tsqr_set_exchange) */
+};
+int enlsip_gn_tsqr_get_transport(enlsip_gn_handle h, int* transport);
 
 /* ---- instrumentation: HIP-event time (ms) of the stages of the last solve ------------------ */
 enum {
@@ -286,6 +298,13 @@ int enlsip_gn_get_stage_ms(enlsip_gn_handle h, float* ms /* ENLSIP_GN_STAGE_COUN
  * measured with HIP events on the handle's stream (bench.py roofline leg) */
 int enlsip_gn_get_update_stats(enlsip_gn_handle h, float* avg_ms, int64_t* launches,
                                double* algorithmic_bytes);
+/* the same launch by launch (sweep order: one entry per panel, or per panel pair where two panels share a pass): SURVEY 8d
+ * bytes 8 (2 m_k n_k + m_k b + b^2) of the panels the launch applies, and its HIP-event time.  *count = launches recorded;
+ * at most cap entries are written. */
+int enlsip_gn_get_update_table(enlsip_gn_handle h, int64_t cap, double* algorithmic_bytes, float* ms, int64_t* count);
+/* GB/s (read + write) of an in-place non-temporal read-modify-write stream over `bytes` of the handle's scratch memory with the
+ * trailing update's access shape, HIP events around `reps` passes: the same-box ceiling of an in-place update (bench.py) */
+int enlsip_gn_measure_stream(enlsip_gn_handle h, int64_t bytes, int reps, double* gbytes_per_s);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ cp $O/ks/*/*kernel_stats.csv $O/c2_kernel_stats_bench_steps3.csv
 python3 - <<PY
 import csv, glob, json
 f = glob.glob("$O/ks/*/*kernel_trace.csv")[0]
-rows = [r for r in csv.DictReader(open(f)) if "k_caqr_update_v4<8, false>" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "k_caqr_update_v4_pair<8>" in r["Kernel_Name"]]
 by = {}
 for r in rows:
     nb = int(r["Grid_Size_Z"]); by.setdefault(nb, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

@@ -11,7 +11,9 @@ per v_mfma_f64_16x16x4_f64 and SIMD (calibrated on k_jq1_v2's known MFMA count, 
 utilisation = busy cycles / (kernel cycles x 1024 SIMDs)."""
 import csv, json, sys
 
-KERNELS = {"k_caqr_update_v4<8, false>": "k_caqr_update_v4<8,false> (level-0 trailing update)", "k_jq1_v2<8, 4, 2>": "k_jq1_v2<8,4,2> (J*Q1)"}
+KERNELS = {"k_caqr_update_v4_pair<8>": "k_caqr_update_v4_pair<8> (level-0 far update, two panels per pass)",
+           "k_caqr_update_v4<8, false>": "k_caqr_update_v4<8,false> (level-0 update of one panel: the pair's second panel's columns)",
+           "k_jq1_v2<8, 4, 2>": "k_jq1_v2<8,4,2> (J*Q1)"}
 SIMDS = 1024
 
 
@@ -27,6 +29,8 @@ def main():
     busy_csv, gui_csv = sys.argv[1], sys.argv[2]
     out = {"kernels": {}}
     for key, label in KERNELS.items():
+        if not any(key in r["Kernel_Name"] for r in csv.DictReader(open(busy_csv))):
+            continue
         b = largest(busy_csv, "SQ_VALU_MFMA_BUSY_CYCLES", key)
         g = largest(gui_csv, "GRBM_GUI_ACTIVE", key)
         cyc = g["per_launch"] / 8.0

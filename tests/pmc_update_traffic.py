@@ -7,11 +7,15 @@
 
 Counters are collected in separate passes (one counter per run) and corrected as MI355X_MICROARCH.md's HBM / rocprofv3 section
 prescribes for gfx950: FETCH_SIZE (KB) tallies 128-byte read requests at 64 bytes -> doubled; WRITE_SIZE (KB) as reported.
-The timed step runs as two pipelined halves, so the launches of the LAST 2 x 14 level-0 updates are taken and normalised to the
-14 whole-batch launches that bench.py's roofline leg times: bytes per launch = sum over the 28 half launches / 14."""
+The timed step runs as two pipelined halves, so the launches of the LAST 2 x L level-0 far updates are taken and normalised to the
+L whole-batch launches that bench.py's roofline leg times (L = 7 pair launches for C2, 14 with ENLSIP_GN_PAIR=0): bytes per launch =
+sum over the 2 L half launches / L.  The algorithmic bytes of a pair launch are SURVEY 8d's B_trail of BOTH panels on the far columns
+(the pass moves about half of that: ratio ~ 0.55)."""
 import csv, hashlib, json, os, sys
 
-KERNEL = "k_caqr_update_v4<8, false>"
+KERNEL_PAIR = "k_caqr_update_v4_pair<8>"
+KERNEL_PLAIN = "k_caqr_update_v4<8, false>"
+KERNEL = KERNEL_PAIR
 
 
 def last_launches(path, counter, count):
@@ -28,20 +32,28 @@ def main():
     fpath, wpath = sys.argv[1], sys.argv[2]
     out = sys.argv[3] if len(sys.argv) > 3 else None
     batch = int(sys.argv[4]) if len(sys.argv) > 4 else 384
+    global KERNEL
     m, n, t, PB = 4096, 512, 64, 32
     npan = (n - t + PB - 1) // PB
-    nl = 2 * (npan)                       # two halves x panels with a trailing update (the last panel carries only d)
+    paired = any(KERNEL_PAIR in r["Kernel_Name"] for r in csv.DictReader(open(fpath)))
+    KERNEL = KERNEL_PAIR if paired else KERNEL_PLAIN
+    btrail = lambda k, ncols: batch * 8.0 * (2.0 * (m - k * PB) * ncols + (m - k * PB) * PB + PB * PB)
+    per_launch_alg = []
+    if paired:
+        for k in range(0, npan - 1, 2):
+            nfar = (n - t) + 1 - (k + 2) * PB                 # columns beyond the pair, incl. the carried right-hand side
+            per_launch_alg.append(btrail(k, nfar) + btrail(k + 1, nfar))
+        # (an odd last panel would be a plain launch of the other kernel: not at C2's 14 panels)
+    else:
+        for k in range(npan):
+            per_launch_alg.append(btrail(k, (n - t) - (k + 1) * PB + 1))
+    L = len(per_launch_alg)
+    nl = 2 * L                            # two pipelined halves
     fetch = last_launches(fpath, "FETCH_SIZE", nl)
     write = last_launches(wpath, "WRITE_SIZE", nl)
     assert len(fetch) == nl and len(write) == nl, (len(fetch), len(write), nl)
-    hbm = (2.0 * sum(fetch) + sum(write)) * 1024.0 / npan
-    alg = 0.0
-    for k in range(npan):
-        mk = m - k * PB
-        ntrail = (n - t) - (k + 1) * PB + 1          # remaining columns of J2 plus the carried right-hand side
-        if ntrail > 0:
-            alg += batch * 8.0 * (2.0 * mk * ntrail + mk * PB + PB * PB)
-    alg /= npan
+    hbm = (2.0 * sum(fetch) + sum(write)) * 1024.0 / L
+    alg = sum(per_launch_alg) / L
     rec = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --steps 1 --warmup 1 --cpu-budget 0 --no-roofline",
            "kernel": KERNEL, "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
            "correction": "gfx950: FETCH_SIZE doubled (128-B requests tallied at 64 B), WRITE_SIZE as reported",

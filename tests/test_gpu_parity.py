@@ -259,7 +259,14 @@ def test_shape_sweep_register_paths(kind, m, n, t, solver):
         compare(out, ref, m, n)
     else:
         assert out.rankA == ref.rankA and out.rankJ2 == ref.rankJ2 and out.code == ref.code
+        assert np.array_equal(out.jpvtA, ref.jpvtA)
         assert rel(out.p, ref.p) <= (1e-6 if kind == "graded" else 1e-9)
+        if ref.code == 1:       # full-rank A: J2 is well defined, so are the leading pivots and |d| of the truncated factorisation
+            r = ref.rankJ2
+            assert np.array_equal(out.jpvtJ2[:r], ref.jpvtJ2[:r])
+            assert sorted(out.jpvtJ2[r:]) == sorted(ref.jpvtJ2[r:])
+            assert abs(np.linalg.norm(out.d) - np.linalg.norm(ref.d)) <= 1e-12 * np.linalg.norm(ref.d)
+            assert np.abs(np.abs(out.d[:r]) - np.abs(ref.d[:r])).max() <= 1e-6 * np.abs(ref.d).max()
 
 
 @pytest.mark.parametrize("kind,m,n,t", [
@@ -498,15 +505,24 @@ def _newton_reference(J, rx, A, cx, Gam):
     m, n = J.shape
     t = A.shape[0]
     ref = go.gn_subproblem(J, rx, A, cx)
-    assert ref.rankA == t
+    r = ref.rankA
     Q1 = ref.F_A.Q_mul(np.eye(n))
-    b = -cx[ref.F_A.p - 1]
-    p1 = np.linalg.solve(np.triu(ref.F_A.R)[:t, :t].T, b) if t else np.zeros(0)
-    if t == n:
+    if r == t:
+        b = -cx[ref.F_A.p - 1]
+        p1 = np.linalg.solve(np.triu(ref.F_A.R)[:t, :t].T, b) if t else np.zeros(0)
+    else:                           # :371-373
+        b = ref.F_L11.Qt_mul(-cx[ref.F_A.p - 1])
+        dp1 = np.linalg.solve(np.triu(ref.F_L11.R)[:r, :r], b[:r])
+        p1 = ref.F_L11.P[:r, :r] @ dp1
+    if r == n:
         return p1, False            # :374-376: with rankA == n the reference returns p1 as it is (no F_A.Q applied)
     JQ1 = J @ Q1
-    J1, J2 = JQ1[:, :t], JQ1[:, t:]
+    J1, J2 = JQ1[:, :r], JQ1[:, r:]
     E = Q1.T @ Gam @ Q1
+    if t > r:                       # :396-399 (needs t >= n: F_L11.p has min(n, t) entries)
+        vp = ref.F_L11.p - 1
+        E = E[np.ix_(vp, vp)]
+    t = r
     W22 = E[t:, t:] + J2.T @ J2
     W21 = E[t:, :t] + J2.T @ J1
     d = -W21 @ p1 - J2.T @ rx
@@ -542,6 +558,30 @@ def test_newton_direction_on_device(m, n, t, solver):
             assert err == errr and (errr or rel(p, pr) <= 1e-10)
     # the resident factors are still those of the solve
     assert np.array_equal(solver.factor(0).p, go.gn_subproblem(J, rx, A, cx).jpvtA)
+
+
+def test_newton_direction_rank_deficient_working_set(solver):
+    """t >= n > rankA: the E[F_L11.p, F_L11.p] branch of newton_search_direction (:371-373, :396-399) on the device against the same
+    lines in NumPy; with n > t > rankA the reference runs out of bounds and the entry point refuses."""
+    from enlsip_gn import GNError
+    rng = np.random.default_rng(77)
+    m, n, t, r = 50, 7, 9, 4
+    J, rx, _, _ = synth.make_problem(515, m, n, 0)
+    A = rng.standard_normal((t, r)) @ rng.standard_normal((r, n))       # rank 4 < n <= t
+    cx = rng.standard_normal(t)
+    S = rng.standard_normal((n, n))
+    Gam = 0.3 * (S + S.T) + 5.0 * np.eye(n)
+    out = solver.solve(J, rx, A, cx)
+    assert (out.rankA, out.code) == (r, -1)
+    p, err = solver.newton_direction(Gam)
+    pr, errr = _newton_reference(J, rx, A, cx, Gam)
+    assert err == errr and not errr and rel(p, pr) <= 1e-9
+    # n > t > rankA: refused
+    A2 = rng.standard_normal((5, 3)) @ rng.standard_normal((3, n))
+    out = solver.solve(J, rx, A2, rng.standard_normal(5))
+    assert out.rankA == 3
+    with pytest.raises(GNError):
+        solver.newton_direction(Gam)
 
 
 def test_argument_errors(solver):

@@ -205,19 +205,22 @@ def test_tsqr_driver_with_real_ranks_on_the_device(world):
 
 @pytest.mark.gpu
 def test_solve_tsqr_through_a_one_rank_rccl_communicator():
-    """The RCCL leg of enlsip_gn_solve_tsqr on the one GPU there is: unique id, ncclCommInitRank with one rank, ncclAllGather on
-    the handle's stream — against the oracle.  (More ranks need one GPU each: tests/tsqr_rank_worker.py with TSQR_BACKEND=nccl.)"""
+    """The RCCL leg of enlsip_gn_solve_tsqr on the one GPU there is: unique id, ncclCommInitRank with one rank, and the exchange
+    itself as ncclAllGather on the handle's stream (an attached communicator is used even with one rank: a self-gather, so the
+    hand-declared prototype, the ncclFloat64 constant and the element count meet RCCL here) — the handle reports which transport
+    moved the message, and the result is checked against the oracle.  (More ranks need one GPU each: tests/tsqr_rank_worker.py with
+    TSQR_BACKEND=nccl.)  Shapes: n2 = 89 and 300 (CAQR + blocked pivoted QR in the combine stage), n2 = 40 (the one-wave route)."""
     import ctypes as C
     import torch
     from enlsip_gn import GNSolver
-    from enlsip_gn.tsqr import tsqr_solve_lib, tsqr_stage_ms
+    from enlsip_gn.tsqr import tsqr_solve_lib, tsqr_stage_ms, tsqr_transport
     s = GNSolver(device=0)
     try:
         ident = C.create_string_buffer(128)
         assert s._lib.enlsip_gn_tsqr_unique_id(ident) == 0
         s._chk(s._lib.enlsip_gn_tsqr_init_rccl(s._h, ident, 1, 0))
         dev = torch.device("cuda", 0)
-        for (m, n, t) in [(5000, 96, 7), (3000, 300, 0)]:
+        for (m, n, t) in [(5000, 96, 7), (3000, 300, 0), (700, 48, 8)]:
             J, rx, A, cx = synth.make_problem(7700 + m, m, n, t)
             ref = go.gn_subproblem(J, rx, A, cx)
             Jd = torch.tensor(np.ascontiguousarray(J.T), dtype=torch.float64, device=dev)
@@ -233,5 +236,10 @@ def test_solve_tsqr_through_a_one_rank_rccl_communicator():
             assert abs(out.d_norm - np.linalg.norm(ref.d)) <= 1e-12 * np.linalg.norm(ref.d)
             ms = tsqr_stage_ms(s)
             assert ms["local"] > 0 and ms["combine"] > 0
+            assert tsqr_transport(s) == "rccl"
+        # back to no communicator: the same call is a device copy and says so
+        s._chk(s._lib.enlsip_gn_tsqr_set_exchange(s._h, None, None, 1, 0))
+        out2 = tsqr_solve_lib(s, Jd, rd, Ad, cd)
+        assert tsqr_transport(s) == "none" and rel(out2.p, ref.p) <= 1e-11
     finally:
         s.close()
