@@ -103,7 +103,13 @@ static int make_plan(enlsip_gn_handle h, long long batch, long long m, long long
     long long running = 0;
     P.panels.resize(P.npan_max);
     // panel pairs (gn_kernels_caqr.hpp): from three panels on; the reflector-by-reflector A/B path keeps the plain sweep
-    P.pair = h->pair_enabled && !(h->flags & ENLSIP_GN_UPDATE_REFLECTORS) && P.npan_max >= 3;
+    // ... and only where the far update is the bulk of the sweep: the pair costs two extra small launches per two panels
+    // (the first panel's level-0 and tree reflectors on the second panel's 32 columns), which a latency-bound sweep does not
+    // earn back.  Measured (MI355X): 384 x C2 +1.4 % solves/s and C4's 262144 rows 29.7 -> 27.4 ms with pairs, but a single
+    // C2 problem 5.17 -> 5.37 ms, 64 of them 10.35 -> 10.47 ms, a 32768-row C4 shard 16.8 -> 17.2 ms.  Rule: at least ~8192
+    // far-update workgroups in the first pair (tiles x 32-column blocks x problems); ENLSIP_GN_PAIR=1 forces pairs.
+    const long long far_wgs = batch * ((std::max<long long>(m, 1) + 64 * P.RPL - 1) / (64 * P.RPL)) * ((std::max<long long>(n - P.kA, 1) + 31) / 32);
+    P.pair = h->pair_enabled && !(h->flags & ENLSIP_GN_UPDATE_REFLECTORS) && P.npan_max >= 3 && (far_wgs >= 8192 || h->pair_forced);
     const long long mpad = rup(std::max<long long>(m, 1), 32);    // NOT ldw: the skew rows are never touched
     for (int k = 0; k < P.npan_max; ++k) {
         const bool second = P.pair && (k & 1);                    // second panel of the pair (k - 1, k): keeps the first one's tiles
@@ -835,6 +841,7 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         const char* pp = getenv("ENLSIP_GN_PAIR");            // 0: plain sweep, one panel per pass over the trailing matrix (A/B)
         if (pp && pp[0] == '0') h->pair_enabled = false;
         if (pp && pp[0] == '2') h->pair_debug = true;         // 2: pair geometry, but the far columns in two plain passes (A/B)
+        if (pp && (pp[0] == '1' || pp[0] == '2')) h->pair_forced = true;   // 1 / 2: pairs for every shape with three panels or more
         const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");
         if (dm) h->debug_maxpan = atoi(dm);
         const char* ds = getenv("ENLSIP_GN_DEBUG_STAGE");

@@ -90,7 +90,7 @@ struct enlsip_gn_context {
     // a child handle (own stream + workspace) driven by a host thread, so the latency-bound kernels of one half
     // overlap the bandwidth-bound kernels of the other.  Accessors route a problem index to the half that owns it.
     enlsip_gn_context* child = nullptr;
-    bool pair_debug = false;
+    bool pair_debug = false, pair_forced = false;
     int debug_maxpan = -1, debug_stage = -1;
     bool pair_enabled = true;           // ENLSIP_GN_PAIR=0: one panel per pass over the trailing matrix
     bool pipeline = true;               // ENLSIP_GN_PIPELINE=0 disables

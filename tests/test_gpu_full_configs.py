@@ -173,13 +173,35 @@ def test_batch_above_launch_limit_small_shape(solver):
     _check_sample_against_oracle(J, rx, At, cx, p, d, info, jJ, [0, 19999, 20000, 20001, B - 1])
 
 
-@pytest.mark.parametrize("t,with_oracle", [(0, False), (16, True)])
-def test_c4_full_size_eight_row_shards(solver, t, with_oracle):
+@pytest.fixture(scope="module")
+def solver_pairs():
+    """Panel pairs forced (ENLSIP_GN_PAIR=1 at handle creation): a 32768-row shard is below the library's own threshold for them."""
+    import os
+    from enlsip_gn import GNSolver
+    old = os.environ.get("ENLSIP_GN_PAIR")
+    os.environ["ENLSIP_GN_PAIR"] = "1"
+    try:
+        s = GNSolver(device=0)
+    finally:
+        if old is None:
+            del os.environ["ENLSIP_GN_PAIR"]
+        else:
+            os.environ["ENLSIP_GN_PAIR"] = old
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("t,with_oracle,pairs", [(0, False, False), (16, True, False), (0, False, True), (16, False, True)])
+def test_c4_full_size_eight_row_shards(solver, solver_pairs, t, with_oracle, pairs):
     """BASELINE configs[3]: ONE tall Jacobian, m = 262144, n = 1024, rows sharded 8 ways (the shards run one after the other on
     this GPU and are stacked exactly as the all-gather stacks them).  Properties for both variants; the t = 16 variant also
-    against LAPACK's dgeqp3 on the whole 262144 x 1024 matrix (about half a minute of host time)."""
+    against LAPACK's dgeqp3 on the whole 262144 x 1024 matrix (about half a minute of host time).  `pairs`: the same with the
+    CAQR's panel pairs forced for the shards and the stacked problem (the t = 16 stack is the one whose tiles are rotated out
+    exactly: the rounding-dust columns of tests/test_gpu_parity.py::test_tsqr_row_shards_match_single_solve at full size)."""
     from enlsip_gn import workload as wl
     from enlsip_gn.tsqr import tsqr_solve_shards_dev
+    if pairs:
+        solver = solver_pairs
     m, n, G = 262144, 1024, 8
     J, rx, At, cx = wl.make_batch(424242 + t, 1, m, n, t, "cuda:0")
     Jd, rxd = J[0], rx[0]

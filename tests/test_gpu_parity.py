@@ -17,10 +17,24 @@ pytestmark = pytest.mark.gpu
 TOL_P = 1e-11
 
 
-@pytest.fixture(scope="module")
-def solver():
+@pytest.fixture(scope="module", params=["auto", "pairs"])
+def solver(request):
+    """Every test of this module runs twice: with the library's own choice between the plain CAQR sweep and panel pairs (pairs
+    only where the far update dominates: large batches, C4's row count) and with pairs forced for every shape with three panels
+    or more (ENLSIP_GN_PAIR=1 is read when the handle is created), so that the pair geometry, the two-panel update kernel and the
+    accessors on pair-shaped factors meet every shape of the suite."""
     from enlsip_gn import GNSolver
-    s = GNSolver(device=0)
+    old = os.environ.get("ENLSIP_GN_PAIR")
+    if request.param == "pairs":
+        os.environ["ENLSIP_GN_PAIR"] = "1"
+    try:
+        s = GNSolver(device=0)
+    finally:
+        if request.param == "pairs":
+            if old is None:
+                del os.environ["ENLSIP_GN_PAIR"]
+            else:
+                os.environ["ENLSIP_GN_PAIR"] = old
     yield s
     s.close()
 
