@@ -503,10 +503,18 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
         for (int i = 0; i < chunk && it < kp_launch; ++i, ++it) {
             a.blkid = it;
             GN_TRACE(h, "  qrcp block %d", it);
-            // candidates in the registers of one workgroup (kp <= 512), block reflector applied to the still-active columns
-            if (kp_launch <= 256) hipLaunchKernelGGL((k_sb_factor_reg<4, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
-            else if (kp_launch <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((k_sb_factor_reg<8, 8>), dim3((unsigned)P.batch), dim3(512), 0, s, a);
+            // candidates in the registers of one workgroup (kp <= 512), block reflector applied to the still-active columns.
+            // Up to three forms per block, each problem runs in the one that fits its current row count kp - j0
+            // (gn_kernels_qrcp_block_reg.hpp); after `it` blocks every problem has made at least `it` steps, so the large
+            // forms are no longer launched once kp_launch - it fits a smaller one.
+            const int rows_max = kp_launch - it;
+            const dim3 fg((unsigned)P.batch);
+            if (rows_max > 256) {
+                if (kp_launch <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8, 4>), fg, dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((k_sb_factor_reg<8, 8, 4>), fg, dim3(512), 0, s, a);
+            }
+            if (rows_max > 128) hipLaunchKernelGGL((k_sb_factor_reg<4, 8, 2>), fg, dim3(512), 0, s, a);
+            hipLaunchKernelGGL((k_sb_factor_reg<2, 8, 0>), fg, dim3(512), 0, s, a);
             hipLaunchKernelGGL(k_sb_update_blk, ugrid, dim3(256), 0, s, a);
         }
         GN_HIP(hipGetLastError());

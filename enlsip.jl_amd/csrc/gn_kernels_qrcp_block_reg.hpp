@@ -40,8 +40,13 @@ struct SbRegLds {             // bookkeeping of a block: keys, positions, candid
 // RPL: rows of the block kp - j0 <= 64 * RPL.  NWV waves hold NCW = 64 / NWV candidate columns each.  With 16 waves
 // (128 registers per lane) the compiler spills inside the step loop and a step costs 7.7 us; 8 waves x 8 columns
 // run spill-free.
-template <int RPL, int NWV>
-__global__ __launch_bounds__(64 * NWV) void k_sb_factor_reg(SbArgs a) {
+// The row count of a block, kp - j0, shrinks as the factorisation advances, and with it what a step costs and what the
+// workgroup needs: the <7 / 8> forms take the whole register file of a CU (256 registers x 512 threads), the <4> form half of
+// it, the <2> form a quarter.  Every block is therefore launched in up to three forms (run_qrcp_block) and a workgroup runs
+// only in the form that fits its problem's current row count: RPL_LOW = rows-per-lane of the next smaller form launched
+// beside this one (0: none) — problems that fit it are left to it.
+template <int RPL, int NWV, int RPL_LOW = 0>
+__global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k_sb_factor_reg(SbArgs a) {
     constexpr int NCW = SB_KMAX / NWV;
     constexpr int NT = 64 * NWV;
     __shared__ SbRegLds L;
@@ -55,6 +60,9 @@ __global__ __launch_bounds__(64 * NWV) void k_sb_factor_reg(SbArgs a) {
     const int tid = threadIdx.x, ln = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
     const int rows = kp - j0;
+    if (info->blk == a.blkid) return;                     // a larger form has just done this block's steps (and advanced j0)
+    if (rows > 64 * RPL) return;                          // served by a larger form
+    if (RPL_LOW > 0 && rows <= 64 * RPL_LOW) return;      // served by the smaller form launched beside this one
     double* M = a.q.M + prob * a.q.sM;
     double* vn1 = a.q.vn1 + prob * a.q.sVn;
     double* vn2 = a.q.vn2 + prob * a.q.sVn;
