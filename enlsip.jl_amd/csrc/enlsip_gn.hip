@@ -19,6 +19,7 @@
 #include "gn_kernels_q1_v2.hpp"
 #include "gn_kernels_q1_rows.hpp"
 #include "gn_kernels_final_small.hpp"
+#include "gn_kernels_small_fused.hpp"
 #include "gn_kernels_constraint_small.hpp"
 #include "gn_kernels_constraint_dist.hpp"
 #include "gn_kernels_update_v4.hpp"
@@ -714,13 +715,21 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         qa.prob0 = 0;
         // V T' of the fast path lives in the (still unused) working matrix of the pivoted QR
         qa.VT = (P.sM >= (long long)n * KBLK) ? h->qdM : nullptr; qa.sVT = P.sM;
-        if (h->flags & ENLSIP_GN_UPDATE_REFLECTORS) launch_jq1(qa, (int)batch, s);   // plain-FMA A/B partner
+        // one 256-row tile, one narrow panel (C5): J*Q1 and the panel factorisation in ONE launch, the tile handed over in LDS
+        const bool fused = h->fuse_small && !upper_in && !(h->flags & ENLSIP_GN_UPDATE_REFLECTORS) &&
+                           small_fused_applies(m, n, P.kA, n2_launch);
+        if (fused) {
+            CaqrArgs ca = caqr_args(h, 0, P.panels[0].levels[0]);
+            ca.npass = 1;
+            launch_jq1_factor_small(qa, ca, (int)batch, s);
+            GN_HIP(hipGetLastError());
+        } else if (h->flags & ENLSIP_GN_UPDATE_REFLECTORS) launch_jq1(qa, (int)batch, s);   // plain-FMA A/B partner
         else if (launch_jq1_rows(qa, (int)batch, s)) {}                             // small n, few reflectors
         else if (!launch_jq1_v2(qa, (int)batch, s)) launch_jq1_mfma(qa, (int)batch, s);      // regular shapes / general shapes
         mark(2);
-        GN_TRACE(h, "attempt %d n2_launch=%d: J*Q1 done", attempt, n2_launch);
+        GN_TRACE(h, "attempt %d n2_launch=%d: J*Q1 done%s", attempt, n2_launch, fused ? " (fused with the panel factorisation)" : "");
         // 3. CAQR of [J2 | d]
-        if (!upper_in) {
+        if (!upper_in && !fused) {
             rc = run_caqr(h, n2_launch);
             if (rc) return rc;
         }
@@ -850,6 +859,8 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (pp && pp[0] == '0') h->pair_enabled = false;
         if (pp && pp[0] == '2') h->pair_debug = true;         // 2: pair geometry, but the far columns in two plain passes (A/B)
         if (pp && (pp[0] == '1' || pp[0] == '2')) h->pair_forced = true;   // 1 / 2: pairs for every shape with three panels or more
+        const char* fs = getenv("ENLSIP_GN_FUSE_SMALL");     // 0: J*Q1 and the one-tile panel factorisation as two launches (A/B)
+        if (fs && fs[0] == '0') h->fuse_small = false;
         const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");
         if (dm) h->debug_maxpan = atoi(dm);
         const char* ds = getenv("ENLSIP_GN_DEBUG_STAGE");

@@ -91,6 +91,7 @@ struct enlsip_gn_context {
     // overlap the bandwidth-bound kernels of the other.  Accessors route a problem index to the half that owns it.
     enlsip_gn_context* child = nullptr;
     bool pair_debug = false, pair_forced = false;
+    bool fuse_small = true;             // ENLSIP_GN_FUSE_SMALL=0: two launches for J*Q1 + panel factorisation of one-tile problems
     int debug_maxpan = -1, debug_stage = -1;
     bool pair_enabled = true;           // ENLSIP_GN_PAIR=0: one panel per pass over the trailing matrix
     bool pipeline = true;               // ENLSIP_GN_PIPELINE=0 disables

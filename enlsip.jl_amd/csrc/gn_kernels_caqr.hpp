@@ -88,7 +88,6 @@ __device__ __forceinline__ long long caqr_block_row(const CaqrArgs& a, long long
 // NW waves per workgroup; wave w owns the NC = 32 / NW panel columns w + NW cc.  NW = 8 halves the per-step
 // dependency chain of a wave (4 dot products + one 4-way transposed reduction + 4 column updates) and doubles
 // the waves per SIMD that hide it.
-template <int RPL, int NW>
 #ifndef ENLSIP_FACTOR_OCC8
 #define ENLSIP_FACTOR_OCC8 4
 #endif
@@ -98,15 +97,13 @@ template <int RPL, int NW>
 #ifndef ENLSIP_FACTOR_OCC16
 #define ENLSIP_FACTOR_OCC16 8
 #endif
-__global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 ? ENLSIP_FACTOR_OCC8 : (RPL == 4 ? ENLSIP_FACTOR_OCC4 : 2))) void k_caqr_factor(CaqrArgs a) {   // 2nd bound = waves per SIMD
+// The factorisation of one group with the tile in registers.  PRE = true: x already holds the tile (the fused small-problem
+// kernel gn_kernels_small_fused.hpp hands it over without the round trip through HBM).
+template <int RPL, int NW, bool PRE>
+__device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int prob, const ProbState& st, double (&x)[PB / NW][RPL],
+                                                 double (*vsh)[64 * RPL], double* taush, double (*gsh)[PB + 1]) {   // 2nd bound = waves per SIMD
     constexpr int NC = PB / NW;
     constexpr int NT = 64 * NW;
-    __shared__ double vsh[2][64 * RPL];
-    __shared__ double taush[PB];
-    __shared__ double gsh[PB][PB + 1];
-
-    const int prob = blockIdx.y + a.prob0;
-    const ProbState st = a.state[prob];
     const int r0 = a.panel * PB;
     if (r0 >= st.kp) return;
     const int bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
@@ -137,16 +134,17 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 
         return (size_t)(col0 + c) * a.ldw + (size_t)(u0 + i * ustep);
     };
     auto bval = [&](int i) -> bool { return (long long)g * a.F + qh + 2 * i < a.nblocks && qh + 2 * i >= a.skip; };
-    // load the tile: a[cc][i] = element (slot ln + 64 i, column w + NW cc)
-    double x[NC][RPL];
+    // load the tile: x[cc][i] = element (slot ln + 64 i, column w + NW cc)   (PRE: the caller has filled x already)
+    if (!PRE) {
 #pragma unroll
-    for (int cc = 0; cc < NC; ++cc) {
-        const int c = w + NW * cc;
+        for (int cc = 0; cc < NC; ++cc) {
+            const int c = w + NW * cc;
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            // tree levels hold upper triangles; the passenger has entries in every row a reflector touches
-            const bool ok = (c < bwp) && bval(i) && (!tri || dns || (c < bw ? rb <= c : rb < bw));
-            x[cc][i] = ok ? W[ubase(c, i) + lane_off] : 0.0;
+            for (int i = 0; i < RPL; ++i) {
+                // tree levels hold upper triangles; the passenger has entries in every row a reflector touches
+                const bool ok = (c < bwp) && bval(i) && (!tri || dns || (c < bw ? rb <= c : rb < bw));
+                x[cc][i] = ok ? W[ubase(c, i) + lane_off] : 0.0;
+            }
         }
     }
     __syncthreads();
@@ -240,6 +238,17 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 
             }
         }
     }
+}
+
+template <int RPL, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 ? ENLSIP_FACTOR_OCC8 : (RPL == 4 ? ENLSIP_FACTOR_OCC4 : 2))) void k_caqr_factor(CaqrArgs a) {   // 2nd bound = waves per SIMD
+    __shared__ double vsh[2][64 * RPL];
+    __shared__ double taush[PB];
+    __shared__ double gsh[PB][PB + 1];
+    const int prob = blockIdx.y + a.prob0;
+    const ProbState st = a.state[prob];
+    double x[PB / NW][RPL];
+    caqr_factor_core<RPL, NW, false>(a, prob, st, x, vsh, taush, gsh);
 }
 
 // ---------------------------------------------------------------------------------------------
