@@ -51,7 +51,7 @@ typedef double v4_d2 __attribute__((ext_vector_type(2)));
 constexpr int V4_ABLATE = ENLSIP_V4_ABLATE;
 #ifdef ENLSIP_V4_STAMPS         // harness only (tests/microbench/update_bench.hip): phase stamps (100 MHz) of sample workgroups
 __device__ long long g_v4_stamps[8 * 8];
-#define V4_STAMP(i) do { if (blockIdx.x == 3 && blockIdx.y == 5 && (blockIdx.z & 31) == 7 && blockIdx.z < 256 && threadIdx.x == 0) g_v4_stamps[(blockIdx.z >> 5) * 8 + (i)] = wall_clock64(); } while (0)
+#define V4_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 3 && blockIdx.y == 5 && (blockIdx.z & 31) == 7 && blockIdx.z < 256 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_v4_stamps[(blockIdx.z >> 5) * 8 + (i)] = wall_clock64(); } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define V4_STAMP(i) do { } while (0)
 #endif
@@ -276,6 +276,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             }
         }
         if (first_app) V4_STAMP(1);
+        if (!first_app) V4_STAMP(3);          // pair: product 1 of the second pass done
         v4_d2 vb[2][4];                                      // ring over (unit, half)
         if (NGW > 0) issue_v(ai, 0, 0, vb[0]);               // travels during the reduction step
 
@@ -286,9 +287,9 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) stage[w][(16 * it + lq + 4 * r) * PB + 16 * ct + lr] = acc[it][ct][r];
-        if (first_app) V4_STAMP(2);
+        if (first_app && NAP == 1) V4_STAMP(2);
         __syncthreads();
-        if (first_app) V4_STAMP(3);
+        if (first_app && NAP == 1) V4_STAMP(3);
         {
             v4_d4 t = (v4_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -304,6 +305,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         }
         __syncthreads();
         if (first_app) V4_STAMP(4);
+        if (!first_app) V4_STAMP(7);          // pair: second reduction done
 
         // ---- product 2: D^T[col][row pair] += W2^T V^T, even and odd rows of each unit; stored by the last pass,
         //      back into the registers otherwise ---------------------------------------------------------------------
@@ -349,6 +351,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) cf[g][p][ct] = fr[p][ct];
+                if (g == NGW - 1) V4_STAMP(2);   // pair: product 2 of the first pass done
                 continue;
             }
             post(g, fr);
@@ -568,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4_pair(CaqrArgs a) {
     __shared__ __attribute__((aligned(16))) double stage[4][V4_STAGE];
     __shared__ __attribute__((aligned(16))) double W2l[PB * PB];
 
+    V4_STAMP(6);
     if (a.skip_rhs && blockIdx.y == gridDim.y - 1) {
         v4_rhs_body<RPL, true>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l);
         return;

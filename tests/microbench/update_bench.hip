@@ -169,6 +169,18 @@ int main(int argc, char** argv) {
             const float t4 = timeit("pair, far columns", [&] { launch_update_v4(RPL, ap, groups, ntrail - ap.skip_rhs, batch, 0); }, bf);
             printf("  two plain passes %.3f ms   narrow + pair %.3f ms   ratio %.3f\n", t1 + t2, t3 + t4, (t3 + t4) / (t1 + t2));
         }
+#ifdef ENLSIP_V4_STAMPS
+        {
+        // the LAST kernel that ran was the pair's far update: entry 6 -> 0 start -> 1 product 1 (a) -> 4 reduction (a) -> 2 product 2 (a)
+        // -> 3 product 1 (b) -> 7 reduction (b) -> 5 product 2 (b) + stores
+        long long sp[64];
+        CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_v4_stamps), sizeof(sp)));
+        for (int g = 0; g < 8; ++g)
+            printf("PAIR wg (3, 5, %3d): setup %5.2f us | product 1 a %5.2f | reduce a %5.2f | product 2 a %5.2f | product 1 b %5.2f | reduce b %5.2f | product 2 b + stores %5.2f | total %5.2f\n",
+                   32 * g + 7, (sp[g*8+0]-sp[g*8+6])*0.01, (sp[g*8+1]-sp[g*8+0])*0.01, (sp[g*8+4]-sp[g*8+1])*0.01, (sp[g*8+2]-sp[g*8+4])*0.01,
+                   (sp[g*8+3]-sp[g*8+2])*0.01, (sp[g*8+7]-sp[g*8+3])*0.01, (sp[g*8+5]-sp[g*8+7])*0.01, (sp[g*8+5]-sp[g*8+6])*0.01);
+        }
+#endif
     }
     const int reps = 5;
     const double rows_k = (double)nblocks * 32;
