@@ -203,8 +203,10 @@ int enlsip_gn_second_lagrange(enlsip_gn_handle h, int64_t prob, const double* p_
  * W22 = E22 + J2'J2, W21 = E21 + J2'J1 (:405-409), d = -W21 p1 - J2' rx (:411), cholesky((W22 + W22')/2) and the two triangular
  * solves (:414-420), p = F_A.Q [p1; p2] (:421) on the resident F_A, p1, J (J * F_A.Q is recomputed, as at :384).
  * *not_posdef = 1 (and p = 0) when the symmetrised W22 is not positive definite (:417-420: `error = true`).  With rankA == n the
- * reference returns p1 as it is (:374-376); so does this.  Returns -7 for a rank-deficient working set (t > rankA), whose
- * E[F_L11.p, F_L11.p] branch (:400-403) is left to the host. */
+ * reference returns p1 as it is (:374-376); so does this.  A rank-deficient working set (t > rankA) takes the reference's other
+ * branch: p1 = F_L11.P[1:rankA, 1:rankA] * dp1 (:371-373) and E = E[F_L11.p, F_L11.p] (:396-399) — defined for t >= n only,
+ * because F_L11.p has min(n, t) entries and :402-403 read rows up to n; with n > t > rankA the reference runs out of bounds and
+ * this entry point returns -7. */
 int enlsip_gn_newton_direction(enlsip_gn_handle h, int64_t prob, const double* Gamma, int64_t ldg, double* p, int64_t* not_posdef);
 
 /* ---- row-sharded TSQR building blocks (multi-GPU config C4) ----------
