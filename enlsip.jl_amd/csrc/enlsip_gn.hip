@@ -328,7 +328,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     const bool mixed = n2_launch != (int)(P.n - P.kA);
     // HIP events around the level-0 far updates (the dominant kernel) when profiling is on; `bytes` = SURVEY 8d's
     // B_trail = 8 (2 m_k n_k + m_k b + b^2) of every panel the launch applies, on the columns it applies them to
-    auto timed = [&](double bytes, auto&& launch) -> int {
+    auto timed = [&](double bytes, hipStream_t st, auto&& launch) -> int {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->profiling) {
             if (h->upd_used + 2 > h->upd_ev.size()) {
@@ -340,11 +340,11 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             }
             e0 = h->upd_ev[h->upd_used++];
             e1 = h->upd_ev[h->upd_used++];
-            GN_HIP(hipEventRecord(e0, h->stream));
+            GN_HIP(hipEventRecord(e0, st));
         }
         launch();
         if (e1) {
-            GN_HIP(hipEventRecord(e1, h->stream));
+            GN_HIP(hipEventRecord(e1, st));
             h->upd_bytes += (double)P.batch * bytes;
             h->upd_launch_bytes.push_back((double)P.batch * bytes);
         }
@@ -354,11 +354,46 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     // the MFMA update of every trailing column of the window; with the J2 columns filling whole 32-column blocks the carried
     // right-hand side (the 32 j + 1-th column: every panel of C2) would take a block of its own: it gets its own routine as the
     // last block index instead.  With a partial last block (C3: 24 columns) it simply rides in that block.
-    auto update_l0 = [&](CaqrArgs a, const LevelPlan& L, int ncols_window, int ncols_grid) {
+    auto update_l0 = [&](CaqrArgs a, const LevelPlan& L, int ncols_window, int ncols_grid, hipStream_t st) {
         if ((ncols_window - 1) % 32 == 0) {
             a.skip_rhs = 1;
-            launch_update_v4(h->plan.RPL, a, L.groups, ncols_grid - 1, (int)P.batch, h->stream);
-        } else launch_update_v4(h->plan.RPL, a, L.groups, ncols_grid, (int)P.batch, h->stream);
+            launch_update_v4(h->plan.RPL, a, L.groups, ncols_grid - 1, (int)P.batch, st);
+        } else launch_update_v4(h->plan.RPL, a, L.groups, ncols_grid, (int)P.batch, st);
+    };
+    // Look-ahead (chain-bound sweeps: one or a few problems with many tiles — C4): a pair's far update is split into the NEXT
+    // pair's 64 columns (this stream) and the rest (second stream), so that the next pair's chain of small dependent launches
+    // (two level-0 factorisations, their trees, the second panel's own columns) runs beside the bulk of the previous far update
+    // instead of behind it.  Order: chain(K) -> E1 ; [wait E2(K-1)] near(K) ; second stream: wait E1, rest(K) -> E2.
+    const long long far_wgs0 = P.batch * (((long long)mpad + 64 * P.RPL - 1) / (64 * P.RPL)) * ((n2_launch + 31) / 32);
+    const bool la = P.pair && use_mfma && h->lookahead && !mixed && !h->pair_debug && h->debug_stage < 0 && P.batch <= 8 && far_wgs0 >= 8192;
+    hipStream_t sA = h->stream, sB = nullptr;
+    size_t la_ev = 0;
+    hipEvent_t la_prev = nullptr;                 // E2 of the previous pair's rest (second stream), not yet waited for
+    auto la_event = [&](hipEvent_t& e) -> int {
+        if (la_ev >= h->la_events.size()) {
+            hipEvent_t ne;
+            GN_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+            h->la_events.push_back(ne);
+        }
+        e = h->la_events[la_ev++];
+        return 0;
+    };
+    if (la) {
+        if (!h->stream2) {
+            // lowest priority: the chain's small kernels on the main stream must not queue behind the thousands of workgroups
+            // of the bulk update for a free CU slot
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            GN_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
+        }
+        sB = h->stream2;
+    }
+    auto la_join = [&]() -> int {                 // this stream goes on only after the second stream's last far update
+        if (la_prev) {
+            GN_HIP(hipStreamWaitEvent(sA, la_prev, 0));
+            la_prev = nullptr;
+        }
+        return 0;
     };
     for (int k = 0; k < npan;) {
         if (h->debug_maxpan >= 0 && k >= h->debug_maxpan) break;   // ENLSIP_GN_DEBUG_MAXPAN: stop the sweep (debugging aid)
@@ -398,17 +433,62 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             } else if (h->pair_debug) {    // A/B: the same pair geometry, far columns in two plain passes (first panel, then second)
                 CaqrArgs a = caqr_args(h, k, LA[0]);
                 a.win = 2;
-                update_l0(a, LA[0], nfar, ntrail);
+                update_l0(a, LA[0], nfar, ntrail, h->stream);
                 CaqrArgs b0 = caqr_args(h, kb, LB[0]);
-                if (live(5)) update_l0(b0, LB[0], nfar, nfar);
+                if (live(5)) update_l0(b0, LB[0], nfar, nfar, h->stream);
+            } else if (la) {
+                // far columns of the pair in two parts (see above); `far` launches level 0 and the trees on columns
+                // [sub0, sub0 + subn) of the far window
+                auto far = [&](int sub0, int subn, hipStream_t st) -> int {
+                    const int ncw = (subn > 0 ? std::min(subn, nfar - sub0) : nfar - sub0);     // launch shape of the sub-window
+                    CaqrArgs a = caqr_args(h, k, LA[0]);
+                    a.win = 2; a.pair = 1; a.tOff2 = LB[0].tOff; a.sub0 = sub0; a.subn = subn;
+                    // the carried right-hand side is the window's last column: a sub-window that ends before it has J2 columns only
+                    const bool has_rhs = (sub0 + ncw == nfar);
+                    const double by = btrail(k, ncw) + btrail(kb, ncw);
+                    int rc = timed(by, st, [&] {
+                        if (has_rhs) update_l0(a, LA[0], ncw, ncw + (ntrail - nfar), st);
+                        else launch_update_v4(h->plan.RPL, a, LA[0].groups, ncw, (int)P.batch, st);
+                    });
+                    if (rc) return rc;
+                    for (size_t li = 1; li < LA.size(); ++li) {
+                        CaqrArgs t = caqr_args(h, k, LA[li]);
+                        t.win = 2; t.sub0 = sub0; t.subn = subn;
+                        launch_update_v4(h->plan.RPL, t, LA[li].groups, ncw + (ntrail - nfar), (int)P.batch, st);
+                    }
+                    for (size_t li = 1; li < LB.size(); ++li) {
+                        CaqrArgs t = caqr_args(h, kb, LB[li]);
+                        t.sub0 = sub0; t.subn = subn;
+                        launch_update_v4(h->plan.RPL, t, LB[li].groups, ncw, (int)P.batch, st);
+                    }
+                    return 0;
+                };
+                const int near = 2 * PB;
+                if (nfar <= near) {               // nothing beyond the next pair's columns: one part, this stream
+                    if (int rcj = la_join()) return rcj;
+                    if (int rc = far(0, 0, sA)) return rc;
+                } else {
+                    hipEvent_t e1, e2;
+                    if (int rc = la_event(e1)) return rc;
+                    if (int rc = la_event(e2)) return rc;
+                    GN_HIP(hipEventRecord(e1, sA));                     // the pair's reflectors and T factors are complete
+                    if (int rcj = la_join()) return rcj;                // the previous pair's rest covers the columns `near` touches
+                    if (int rc = far(0, near, sA)) return rc;
+                    GN_HIP(hipStreamWaitEvent(sB, e1, 0));
+                    if (int rc = far(near, 0, sB)) return rc;
+                    GN_HIP(hipEventRecord(e2, sB));
+                    la_prev = e2;
+                }
+                k += 2;
+                continue;
             } else {
                 CaqrArgs a = caqr_args(h, k, LA[0]);
                 a.win = 2; a.pair = 1; a.tOff2 = LB[0].tOff;
-                int rc = timed(btrail(k, nfar) + btrail(kb, nfar), [&] { update_l0(a, LA[0], nfar, ntrail); });
+                int rc = timed(btrail(k, nfar) + btrail(kb, nfar), h->stream, [&] { update_l0(a, LA[0], nfar, ntrail, h->stream); });
                 if (rc) return rc;
                 if (mixed) {        // problems whose J2 ends before the second panel: the first panel alone, every trailing column
                     a.pair = 2;
-                    update_l0(a, LA[0], nfar, ntrail);
+                    update_l0(a, LA[0], nfar, ntrail, h->stream);
                 }
             }
             for (size_t li = 1; li < LA.size() && live(6); ++li) {
@@ -424,6 +504,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             continue;
         }
         // ---- one panel ----
+        if (int rcj = la_join()) return rcj;
         // last panel narrower than 32 with d as the only trailing column: d rides through the factor kernels
         const bool passenger = (ntrail == 1 && bwk < PB && kp_launch == n2_launch);
         for (const LevelPlan& L : P.panels[k].levels) {
@@ -432,7 +513,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             launch_factor(h, a, L.groups);
             if (ntrail > 0 && !passenger) {
                 if (use_mfma && L.level == 0) {
-                    int rc = timed(btrail(k, ntrail), [&] { update_l0(a, L, ntrail, ntrail); });
+                    int rc = timed(btrail(k, ntrail), h->stream, [&] { update_l0(a, L, ntrail, ntrail, h->stream); });
                     if (rc) return rc;
                 } else if (use_mfma) launch_update_v4(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
                 else launch_update_refl(h, a, L.groups, ntrail);
@@ -440,6 +521,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         }
         ++k;
     }
+    if (int rcj = la_join()) return rcj;
     GN_HIP(hipGetLastError());
     return 0;
 }
@@ -859,6 +941,8 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (pp && pp[0] == '0') h->pair_enabled = false;
         if (pp && pp[0] == '2') h->pair_debug = true;         // 2: pair geometry, but the far columns in two plain passes (A/B)
         if (pp && (pp[0] == '1' || pp[0] == '2')) h->pair_forced = true;   // 1 / 2: pairs for every shape with three panels or more
+        const char* lk = getenv("ENLSIP_GN_LOOKAHEAD");      // 0: the pair sweep on one stream (A/B)
+        if (lk && lk[0] == '0') h->lookahead = false;
         const char* fs = getenv("ENLSIP_GN_FUSE_SMALL");     // 0: J*Q1 and the one-tile panel factorisation as two launches (A/B)
         if (fs && fs[0] == '0') h->fuse_small = false;
         const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");
@@ -915,6 +999,8 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->sub) (void)enlsip_gn_destroy(h->sub);
     if (h->child) (void)enlsip_gn_destroy(h->child);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;

@@ -52,6 +52,8 @@ struct CaqrArgs {
     // trailing update only:
     int win;            // 0: every trailing column; 1: only the columns of the NEXT panel (narrow update inside a pair);
                         // 2: every trailing column BEYOND the next panel's columns (far update of a pair's first panel)
+    int sub0, subn;     // a sub-range of the column window: skip sub0 columns, then at most subn (0: to the end).  The look-ahead
+                        // sweep splits a pair's far update into the next pair's columns (first) and the rest (on a second stream)
     int pair;           // level-0 far update: 1 = the workgroup also applies the level-0 reflectors of panel + 1 (T blocks from
                         // tOff2) to its block of C while it sits in registers: one pass over the trailing matrix for two panels
     long long tOff2;
@@ -284,6 +286,8 @@ __global__ __launch_bounds__(256) void k_caqr_update_refl(CaqrArgs a) {
             if (a.win == 1) ncols = bwn;
             else { first += bwn; ncols -= bwn; }
         }
+        first += a.sub0; ncols -= a.sub0;
+        if (a.subn > 0 && ncols > a.subn) ncols = a.subn;
         C = a.W + prob * a.sW + (size_t)(st.rankA + first) * a.ldw;
     }
     const int cbase = blockIdx.y * 32;

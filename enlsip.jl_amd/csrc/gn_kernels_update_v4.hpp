@@ -510,6 +510,8 @@ __device__ __forceinline__ bool v4_setup(const CaqrArgs& a, V4Ctx& c, int& nvu, 
     ncols = st.n2 + 1 - first - ((!TRI && a.skip_rhs) ? 1 : 0);
     if (a.win == 1) ncols = bwn;
     else if (a.win == 2) { first += bwn; ncols -= bwn; }
+    first += a.sub0; ncols -= a.sub0;                                    // sub-range of the window (look-ahead sweep)
+    if (a.subn > 0 && ncols > a.subn) ncols = a.subn;
     c.cb0 = blockIdx.y * ENLSIP_V4_CW;
     if (c.cb0 >= ncols) return false;
     c.rows_valid = 0;

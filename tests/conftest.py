@@ -23,3 +23,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: let PyTorch initialise its HIP runtime BEFORE the library does.  torch ships its own ROCm libraries and the
+    library links the system's; in one process the runtime that comes up second after the other has claimed the device reports
+    "No HIP GPUs are available" when that second one is torch's (seen with `-k tsqr`, where the first GPU call used to be the
+    library's).  bench.py imports torch first for the same reason."""
+    if not any(item.get_closest_marker("gpu") for item in items):
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda:0")
+    except Exception:
+        pass
