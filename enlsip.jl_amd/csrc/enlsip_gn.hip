@@ -1087,7 +1087,7 @@ int enlsip_gn_measure_stream(enlsip_gn_handle h, int64_t bytes, int reps, double
     GN_CATCH(h)
 }
 
-// debugging aid (not part of include/enlsip_gn.h): the working matrix W (ldw x (n + 1)) of problem `prob` as it stands
+// debugging aid: the working matrix W (ldw x (n + 1)) of problem `prob` as it stands
 int enlsip_gn_debug_copy_W(enlsip_gn_handle h, int64_t prob, double* out, int64_t* ldw_out, int64_t cap_doubles) {
     if (!h || !h->have_plan) return -1;
     const Plan& P = h->plan;

@@ -307,6 +307,11 @@ int enlsip_gn_get_update_table(enlsip_gn_handle h, int64_t cap, double* algorith
 /* GB/s (read + write) of an in-place non-temporal read-modify-write stream over `bytes` of the handle's scratch memory with the
  * trailing update's access shape, HIP events around `reps` passes: the same-box ceiling of an in-place update (bench.py) */
 int enlsip_gn_measure_stream(enlsip_gn_handle h, int64_t bytes, int reps, double* gbytes_per_s);
+/* Debugging aid (tests/pair_probe_w*.py): copies the working matrix W of problem `prob` (ldw x (n + 1): J*Q1 with the CAQR factors of
+ * [J2 | d] in place) as it stands to host memory; *ldw_out = its leading dimension; -3 when cap_doubles is too small.  Together with
+ * ENLSIP_GN_DEBUG_MAXPAN / ENLSIP_GN_DEBUG_STAGE (stop the CAQR sweep after so many panels / inside the first pair) this is how an
+ * orthogonality defect is located stage by stage. */
+int enlsip_gn_debug_copy_W(enlsip_gn_handle h, int64_t prob, double* out, int64_t* ldw_out, int64_t cap_doubles);
 
 #ifdef __cplusplus
 }

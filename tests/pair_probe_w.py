@@ -22,7 +22,7 @@ def child(tag, maxpan):
     ldw = C.c_int64(0)
     cap = (m + 64) * (n + 1)
     buf = np.zeros(cap)
-    rc = s._lib.enlsip_gn_debug_copy_W(s._h, C.c_int64(0), buf.ctypes.data_as(C.c_void_p), C.byref(ldw), C.c_int64(cap))
+    rc = s._lib.enlsip_gn_debug_copy_W(s._h, 0, buf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ldw), cap)
     assert rc == 0, rc
     W = buf[: ldw.value * (n + 1)].reshape(n + 1, ldw.value).T[:m, :]
     np.save(f"/tmp/w_{tag}_{maxpan}.npy", W)
