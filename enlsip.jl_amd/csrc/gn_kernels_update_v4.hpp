@@ -56,6 +56,9 @@ __device__ long long g_v4_stamps[8 * 8];
 #define V4_STAMP(i) do { } while (0)
 #endif
 
+#ifndef ENLSIP_V4_PREFETCH_NEXT
+#define ENLSIP_V4_PREFETCH_NEXT 1
+#endif
 constexpr int V4_LD = 34;                    // leading dimension of the per-wave transpose images
 constexpr int V4_IMG = PB * V4_LD;           // doubles per image (C or V), 32 columns
 constexpr int V4_STAGE = 2 * V4_IMG;         // per wave: C image + V image (also hosts the wave's W1 partial)
@@ -191,6 +194,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     // a unit permuted (row 2 lr + p -> slot lr + 16 p, in BOTH images: the contraction index of product 1 may be any
     // bijection), so that no pass needs the block in two register layouts at once.
     v4_d4 cf[NAP > 1 ? (NGW > 0 ? NGW : 1) : 1][2][2];
+    v4_d2 vnext[2][4];                       // NAP > 1: V of the NEXT pass's first unit, requested during the last unit of product 2
 #pragma unroll
     for (int ai = 0; ai < NAP; ++ai) {
         const bool first_app = (ai == 0), last_app = (ai == NAP - 1);
@@ -209,8 +213,13 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         }
         if (NGW > 0) {
             v4_d2 vp[2][4];
-            issue_v(ai, 0, 0, vp[0]);
-            issue_v(ai, 0, 1, vp[1]);
+            if (first_app || !ENLSIP_V4_PREFETCH_NEXT) {
+                issue_v(ai, 0, 0, vp[0]);
+                issue_v(ai, 0, 1, vp[1]);
+            } else {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) { vp[0][k4] = vnext[0][k4]; vp[1][k4] = vnext[1][k4]; }
+            }
             if (first_app) {
                 issue_c(0);
                 if (NGW > 1) issue_c(1);
@@ -323,6 +332,10 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                     if (first_app) fr[p][ct] = (v4_d4){cp[g][ct][0][p], cp[g][ct][1][p], cp[g][ct][2][p], cp[g][ct][3][p]};
                     else fr[p][ct] = cf[g][p][ct];
                 }
+            if (ENLSIP_V4_PREFETCH_NEXT && !last_app && g == NGW - 1) {       // the next pass's first unit of V travels during this unit
+                issue_v(ai + 1, 0, 0, vnext[0]);
+                issue_v(ai + 1, 0, 1, vnext[1]);
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int u = 2 * g + h;                     // piece index; piece u + 1 is fetched while u is used
