@@ -982,6 +982,7 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);      // look-ahead sweep: an error return may have left work there
     if (h->ws.p) (void)hipFree(h->ws.p);
     if (h->in_stage.p) (void)hipFree(h->in_stage.p);
     if (h->out_stage.p) (void)hipFree(h->out_stage.p);
