@@ -365,7 +365,8 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     // (two level-0 factorisations, their trees, the second panel's own columns) runs beside the bulk of the previous far update
     // instead of behind it.  Order: chain(K) -> E1 ; [wait E2(K-1)] near(K) ; second stream: wait E1, rest(K) -> E2.
     const long long far_wgs0 = P.batch * (((long long)mpad + 64 * P.RPL - 1) / (64 * P.RPL)) * ((n2_launch + 31) / 32);
-    const bool la = P.pair && use_mfma && h->lookahead && !mixed && !h->pair_debug && h->debug_stage < 0 && P.batch <= 8 && far_wgs0 >= 8192;
+    const bool la = P.pair && use_mfma && h->lookahead && !mixed && !h->pair_debug && h->debug_stage < 0 &&
+                    ((P.batch <= 8 && far_wgs0 >= 8192) || h->lookahead_forced);
     hipStream_t sA = h->stream, sB = nullptr;
     size_t la_ev = 0;
     hipEvent_t la_prev = nullptr;                 // E2 of the previous pair's rest (second stream), not yet waited for
@@ -943,6 +944,7 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (pp && (pp[0] == '1' || pp[0] == '2')) h->pair_forced = true;   // 1 / 2: pairs for every shape with three panels or more
         const char* lk = getenv("ENLSIP_GN_LOOKAHEAD");      // 0: the pair sweep on one stream (A/B)
         if (lk && lk[0] == '0') h->lookahead = false;
+        if (lk && lk[0] == '1') h->lookahead_forced = true;   // 1: for every paired sweep (tests)
         const char* fs = getenv("ENLSIP_GN_FUSE_SMALL");     // 0: J*Q1 and the one-tile panel factorisation as two launches (A/B)
         if (fs && fs[0] == '0') h->fuse_small = false;
         const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");

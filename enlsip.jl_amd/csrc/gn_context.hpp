@@ -91,6 +91,7 @@ struct enlsip_gn_context {
     // overlap the bandwidth-bound kernels of the other.  Accessors route a problem index to the half that owns it.
     enlsip_gn_context* child = nullptr;
     bool pair_debug = false, pair_forced = false;
+    bool lookahead_forced = false;
     bool lookahead = true;              // ENLSIP_GN_LOOKAHEAD=0: chain-bound pair sweeps on one stream
     hipStream_t stream2 = nullptr;      // second stream of the look-ahead sweep (the bulk of a pair's far update)
     std::vector<hipEvent_t> la_events;

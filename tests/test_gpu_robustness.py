@@ -1,6 +1,8 @@
 """Robustness of the HIP path (GPU): one handle reused across random shapes with degenerate / non-finite inputs (two GPU memory
 faults were found this way, profiles/r1_notes.md), and padded leading dimensions / strides on the device entry.  Longer versions:
 tests/stress_reuse.py, tests/ld_padding.py, tests/stress_pipelined.py, tests/stress_tsqr.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -243,3 +245,95 @@ def test_solve_tsqr_through_a_one_rank_rccl_communicator():
         assert tsqr_transport(s) == "none" and rel(out2.p, ref.p) <= 1e-11
     finally:
         s.close()
+
+
+def _solver_with_env(**env):
+    """A handle created under the given environment switches (they are read at enlsip_gn_create)."""
+    from enlsip_gn import GNSolver
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return GNSolver(device=0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,t", [(9000, 200, 8), (20000, 330, 0), (5000, 96, 3)])
+def test_lookahead_sweep_matches_the_one_stream_sweep(m, n, t):
+    """Pairs with look-ahead forced (ENLSIP_GN_PAIR=1, ENLSIP_GN_LOOKAHEAD=1: the far update of a pair split over two streams with
+    events between them) against the oracle and against the same sweep on one stream: R0 and p must not depend on the schedule."""
+    J, rx, A, cx = synth.make_problem(6100 + m + n, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    outs = []
+    for la in (1, 0):
+        s = _solver_with_env(ENLSIP_GN_PAIR=1, ENLSIP_GN_LOOKAHEAD=la)
+        try:
+            for _ in range(2):                  # twice on one handle: events and the second stream are reused
+                out = s.solve(J, rx, A, cx)
+            outs.append(out)
+        finally:
+            s.close()
+        assert rel(out.p, ref.p) <= 1e-11 and (out.rankA, out.rankJ2) == (ref.rankA, ref.rankJ2)
+        assert np.array_equal(out.jpvtJ2, ref.jpvtJ2)
+        assert abs(np.linalg.norm(out.d) - np.linalg.norm(ref.d)) <= 1e-12 * np.linalg.norm(ref.d)
+    assert np.array_equal(outs[0].p, outs[1].p) and np.array_equal(outs[0].d, outs[1].d)     # same kernels on the same data: bit for bit
+
+
+@pytest.mark.gpu
+def test_fused_small_kernel_matches_the_two_launch_form():
+    """One-tile problems with one narrow panel (C5's shape and neighbours): J*Q1 + panel in one launch (default) and as two launches
+    (ENLSIP_GN_FUSE_SMALL=0) give the same factors, bit for bit — the fused kernel runs the same factorisation body on the same
+    numbers — and both match the oracle; shapes outside the fused kernel's range (n2 = 32, m > 256) take the two-launch form."""
+    import torch
+    from enlsip_gn import workload as wl
+    for (m, n, t, batch) in [(256, 32, 4, 64), (200, 30, 7, 40), (256, 32, 0, 16), (130, 17, 16, 33), (300, 32, 4, 8)]:
+        J, rx, At, cx = wl.make_batch(4400 + m + n + t, batch, m, n, t, "cuda:0")
+        res = []
+        for fuse in (1, 0):
+            s = _solver_with_env(ENLSIP_GN_FUSE_SMALL=fuse)
+            try:
+                p = torch.zeros((batch, n), dtype=torch.float64, device="cuda:0")
+                d = torch.zeros((batch, m), dtype=torch.float64, device="cuda:0")
+                jJ = torch.zeros((batch, n), dtype=torch.int64, device="cuda:0")
+                torch.cuda.synchronize()
+                s.solve_batched_dev(batch, m, n, t, J.data_ptr(), m, m * n, rx.data_ptr(), At.data_ptr() if t else 0, max(n, 1), n * t,
+                                    cx.data_ptr() if t else 0, dp=p.data_ptr(), dd=d.data_ptr(), djJ=jJ.data_ptr())
+                res.append((p.cpu().numpy(), d.cpu().numpy(), jJ.cpu().numpy()))
+            finally:
+                s.close()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+        for k in (0, batch - 1):
+            Jh = J[k].cpu().numpy().T
+            ref = go.gn_subproblem(Jh, rx[k].cpu().numpy(), At[k].cpu().numpy().reshape(t, n), cx[k].cpu().numpy())
+            assert rel(res[0][0][k], ref.p) <= 1e-11
+
+
+@pytest.mark.gpu
+def test_update_table_and_stream_ceiling():
+    """Instrumentation of bench.py: the far-update launches one by one (SURVEY 8d bytes and HIP-event time; pairs: one launch per
+    two panels) and the in-place stream measurement."""
+    import torch
+    from enlsip_gn import workload as wl
+    m, n, t, batch = 2048, 256, 32, 96
+    J, rx, At, cx = wl.make_batch(1234, batch, m, n, t, "cuda:0")
+    p = torch.zeros((batch, n), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    for pair, launches in ((1, 4), (0, 7)):          # n2 = 224 = 7 full panels: pairs (0,1) (2,3) (4,5) + the seventh alone (d is its one trailing column)
+        s = _solver_with_env(ENLSIP_GN_PAIR=pair)
+        try:
+            s.set_profiling(True)
+            s.solve_batched_dev(batch, m, n, t, J.data_ptr(), m, m * n, rx.data_ptr(), At.data_ptr(), n, n * t, cx.data_ptr(), dp=p.data_ptr())
+            avg_ms, cnt, total = s.update_stats()
+            table = s.update_table()
+            assert cnt == len(table) == launches and avg_ms > 0
+            assert abs(sum(b for b, _ in table) - total) <= 1e-9 * total and all(ms > 0 for _, ms in table)
+            if pair:
+                gbs = s.measure_stream(1 << 28, 3)
+                assert 1000.0 < gbs < 8000.0            # an MI355X streams 5-6 TB/s in place; anything else is a broken measurement
+        finally:
+            s.close()
