@@ -26,6 +26,9 @@
 #include "gn_kernels_q1.hpp"
 #include "gn_kernels_update_v4.hpp"
 
+#ifndef ENLSIP_JQ1_PREFETCH_VT
+#define ENLSIP_JQ1_PREFETCH_VT 1
+#endif
 #ifndef ENLSIP_JQ1_ABLATE
 #define ENLSIP_JQ1_ABLATE 0     // timing-only ablations for tests/microbench/jq1_bench.hip: 1 = no MFMAs, 2 = no J loads / W stores,
 #endif                          // 3 = no V staging (wrong results in every non-zero mode)
@@ -219,6 +222,10 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         // ---- phase 2: W1 = sum over waves (slots of waves 4..7, then += waves 0..3), W2 = -W1 T_b ------------
         // partial layout: lane-linear, index ((p * 4 + jg) * 4 + r) * 64 + ln
         JQ1_STAMP(2);
+        // the first Vt tile of phase 3 travels during the reduction (it used to be requested after it: one exposed L2 round trip
+        // per workgroup)
+        v4_d2 vx3[8];
+        if (ENLSIP_JQ1_PREFETCH_VT && tile_on(0)) fetch_vt(w, vx3);
         __syncthreads();                                   // every wave is done with its V image
         JQ1_STAMP(3);
         {
@@ -263,7 +270,12 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
         // ---- phase 3: tile^T += V_b W2^T  (D^T[i = column lq + 4 r][j = row pair lr]) -------------------------
         {
             v4_d2 vx[8];
-            if (tile_on(0)) fetch_vt(w, vx);
+            if (tile_on(0)) {
+                if (ENLSIP_JQ1_PREFETCH_VT) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) vx[q] = vx3[q];
+                } else fetch_vt(w, vx);
+            }
 #pragma unroll
             for (int T = 0; T < NTW; ++T) {
                 const int tile = w + Q2_NW * T;
