@@ -161,21 +161,25 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
                 const int buf = j & 1;
                 if (w == jw) {
                     // reflector of column j: pivot slot dj = j + dsh lives in lane dj, register 0
+                    // dj = j + 32 skip <= 63: only register 0 (slots 0..63) can hold the diagonal or rows above it, the slots
+                    // of registers i >= 1 are all below it — no row masks there (the owner's part is the step's critical path)
                     const int dj = j + dsh;
-                    double xn2 = 0.0;
+                    double xn2 = (lnl > dj) ? x[jj][0] * x[jj][0] : 0.0;
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i)
-                        if (lnl + 64 * i > dj) xn2 += x[jj][i] * x[jj][i];
+                    for (int i = 1; i < RPL; ++i) xn2 += x[jj][i] * x[jj][i];
                     xn2 = wave_allsum(xn2);
                     const double alpha = wave_bcast(x[jj][0], dj);
                     const Reflector h = make_reflector(alpha, xn2);
+                    {
+                        const double v = (lnl > dj) ? x[jj][0] * h.scale : (lnl == dj ? 1.0 : 0.0);
+                        vsh[buf][lnl] = v;
+                        x[jj][0] = (lnl > dj) ? v : (lnl == dj ? h.beta : x[jj][0]);
+                    }
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i) {
-                        const int s = lnl + 64 * i;
-                        const double v = (s > dj) ? x[jj][i] * h.scale : (s == dj ? 1.0 : 0.0);
-                        vsh[buf][s] = v;
-                        if (s > dj) x[jj][i] = v;
-                        if (s == dj) x[jj][i] = h.beta;
+                    for (int i = 1; i < RPL; ++i) {
+                        const double v = x[jj][i] * h.scale;
+                        vsh[buf][lnl + 64 * i] = v;
+                        x[jj][i] = v;
                     }
                     if (lnl == 0) taush[j] = h.tau;
                 }
