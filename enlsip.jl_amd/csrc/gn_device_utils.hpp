@@ -203,6 +203,14 @@ __device__ __forceinline__ ArgMax wave_argmax(double val, int pos, int idx) {
     return r;
 }
 
+// A value every lane holds identically (an LDS word read at a wave-uniform address) moved to scalar registers: tells the
+// compiler that a branch on it is wave-uniform.  Without it such a branch is compiled as a divergent one (exec masks, flow
+// blocks whose phi nodes copy every live register array: k_sb_factor_reg carried two copies of its candidate block).
+__device__ __forceinline__ int uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ double uniform_f64(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
 // src_lane must be wave-uniform (it is a loop counter everywhere it is used): v_readlane
 __device__ __forceinline__ double wave_bcast(double x, int src_lane) {
     return readlane_f64(x, src_lane);

@@ -164,49 +164,55 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
     stamp(2);
     // ---- 4. pivot steps -------------------------------------------------------------------------------------
     const int smax = (a.Tsb != nullptr) ? 32 - (j0 & 1) : SB_KMAX;   // the blocked update applies <= 32 reflectors at once
+    // The step loop is written in rotated form — the pivot search and the certainty test of step s + 1 close iteration s, the
+    // only exit is at the bottom — because a `break` out of the middle makes the compiler (whose structurizer turns every
+    // loop with lane-dependent branches inside into a single-exit loop) carry the exit copy AND the next-iteration copy of
+    // the whole candidate block through the loop: two register sets, ~200 v_mov_b64 per step.
+    // every wave finds the pivot among the active candidates (identical result in all waves)
+    auto search = [&](int sx, int lnx) -> ArgMax {
+        const int rdx = sx & 1;
+        const int cp = L.cpos[rdx][lnx];               // both words unconditionally (lnx < 64 = SB_KMAX): one LDS round trip
+        const double cv = L.cvn1[rdx][lnx];
+        const bool in = lnx < K && cp >= 0;
+        return wave_argmax(in ? pivot_key(cv) : -1.0, in ? cp : 0x7fffffff, in ? lnx : -1);
+    };
+    // certain iff it beats every column left outside (their current norms are <= bval); the first
+    // step of a block is always certain: rank 0 is the global maximum
+    auto certain = [&](const ArgMax& m, int sx) -> bool { return m.idx >= 0 && (sx == 0 || m.val > uniform_f64(L.bval)); };
     int s = 0;
-    for (;; ++s) {
+    ArgMax am = {-1.0, 0x7fffffff, -1};
+    bool go = j0 < kp && smax > 0;
+    if (go) {
+        am = search(0, ln);
+        go = certain(am, 0);
+    }
+    while (go) {
         // opaque per-iteration copies of the lane / wave ids: without them loop-invariant code motion hoists every row
         // mask and LDS address of the unrolled columns out of the loop and spills them
         int lnl = ln, wl = w;
         asm volatile("" : "+v"(lnl));
         asm volatile("" : "+s"(wl));
         const int j = j0 + s;
-        if (j >= kp || s >= smax) break;
         const int rd = s & 1, wr = rd ^ 1;
-        // every wave finds the pivot among the active candidates (identical result in all waves)
-        double bv = -1.0;
-        int bp = 0x7fffffff, bk = -1;
-        if (lnl < K && L.cpos[rd][lnl] >= 0) {
-            bv = pivot_key(L.cvn1[rd][lnl]);
-            bp = L.cpos[rd][lnl];
-            bk = lnl;
-        }
-        const ArgMax am = wave_argmax(bv, bp, bk);
-        // certain iff it beats every column left outside (their current norms are <= bval); the first
-        // step of a block is always certain: rank 0 is the global maximum
-        if (!(am.idx >= 0 && (s == 0 || am.val > L.bval))) break;
         const int ci = am.idx, q = am.pos;
-        // the owner of the pivot column builds the reflector (rows > s of the column; pivot entry in local row s)
+        // the owner of the pivot column builds the reflector (rows > s of the column; pivot entry in local row s).
+        // It only READS its registers here: the retired column takes its reflector / beta in the apply loop below, where
+        // every x[cc] is modified in place anyway — a conditional write here makes the compiler carry a second copy of the
+        // whole candidate block through the step loop (~290 v_mov_b64 per step).  s < 64: rows of registers i >= 1 are
+        // all below the pivot row, no masks there.
         if (wl == ci % NWV) {
 #pragma unroll
             for (int cc = 0; cc < NCW; ++cc) {
                 if (cc == ci / NWV) {
-                    double xn2 = 0.0;
+                    double xn2 = (lnl > s) ? x[cc][0] * x[cc][0] : 0.0;
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i)
-                        if (lnl + 64 * i > s) xn2 += x[cc][i] * x[cc][i];
+                    for (int i = 1; i < RPL; ++i) xn2 += x[cc][i] * x[cc][i];
                     xn2 = wave_allsum(xn2);
                     const double alpha = row_of(x[cc], s);
                     const Reflector h = make_reflector(alpha, xn2);
+                    L.vsh[rd][lnl] = (lnl > s) ? x[cc][0] * h.scale : (lnl == s ? 1.0 : 0.0);
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i) {
-                        const int r = lnl + 64 * i;
-                        const double v = (r > s) ? x[cc][i] * h.scale : (r == s ? 1.0 : 0.0);
-                        L.vsh[rd][r] = v;
-                        if (r > s) x[cc][i] = v;           // the retired column keeps its reflector below the diagonal
-                        if (r == s) x[cc][i] = h.beta;
-                    }
+                    for (int i = 1; i < RPL; ++i) L.vsh[rd][lnl + 64 * i] = x[cc][i] * h.scale;
                     if (lnl == 0) {
                         L.taul[ci] = h.tau;
                         L.betal[ci] = h.beta;
@@ -220,7 +226,17 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
         double v[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) v[i] = L.vsh[rd][lnl + 64 * i];
-        const double tj = L.tau_s[rd];
+        // everything else this step reads from LDS is fetched here too, in one round trip (the column loop below stores Gram
+        // entries, which would otherwise keep each column's position read behind the previous column's store): positions
+        // of the wave's columns, the owner's beta, the norms of the downdate (lane u < NCW <-> column u)
+        int pkv[NCW];
+#pragma unroll
+        for (int cc = 0; cc < NCW; ++cc) pkv[cc] = L.cpos[rd][wl + NWV * cc];
+        const double beta_o = L.betal[ci];
+        const int u = lnl & (NCW - 1);
+        const int ku = wl + NWV * u;
+        const double o1_in = L.cvn1[rd][ku], o2_in = L.cvn2[ku];
+        const double tj = uniform_f64(L.tau_s[rd]);
         double dot[NCW], ds[NCW];
 #pragma unroll
         for (int cc = 0; cc < NCW; ++cc) {
@@ -237,8 +253,14 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
         for (int cc = 0; cc < NCW; ++cc) {
             const int k = wl + NWV * cc;
             ajc4[cc] = 0.0;
-            if (k >= K || k == ci) continue;
-            const int pk = L.cpos[rd][k];
+            if (k >= K) continue;
+            if (k == ci) {          // the retired column keeps its reflector below the diagonal, beta on it
+                x[cc][0] = (lnl > s) ? v[0] : (lnl == s ? beta_o : x[cc][0]);
+#pragma unroll
+                for (int i = 1; i < RPL; ++i) x[cc][i] = v[i];
+                continue;
+            }
+            const int pk = uniform_i32(pkv[cc]);
             if (pk >= 0) {
                 if (tj != 0.0) {
                     const double wd = tj * ds[cc];
@@ -254,14 +276,12 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
         }
         // dlaqp2 norm downdate of the wave's active columns as ONE instruction stream: lane u < NCW <-> column u
         {
-            const int u = lnl & (NCW - 1);
-            const int ku = wl + NWV * u;
             const bool mine = (lnl < NCW) && ((actm >> u) & 1u);
             double ajc = 0.0;
 #pragma unroll
             for (int cc = 0; cc < NCW; ++cc) ajc = (u == cc) ? ajc4[cc] : ajc;
-            double o1 = mine ? L.cvn1[rd][ku] : 0.0;
-            const double o2 = mine ? L.cvn2[ku] : 1.0;
+            double o1 = mine ? o1_in : 0.0;
+            const double o2 = mine ? o2_in : 1.0;
             bool need = false;
             if (mine && o1 != 0.0) {
                 double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
@@ -291,7 +311,8 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
             }
             if (mine) L.cvn1[wr][ku] = o1;
         }
-        // position bookkeeping (wave 0): pivot at position q <-> column cj that sat at position j
+        // position bookkeeping (wave 0): pivot at position q <-> column cj that sat at position j.  (Done by the owner's
+        // neighbour while the owner builds the reflector instead: no gain, 4.60 -> 4.65 ms per single solve.)
         if (wl == 0) {
             const int pc = L.ccol[ci];
             const int cj = L.colat_l[j];
@@ -310,6 +331,12 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
             }
         }
         __syncthreads();
+        ++s;
+        go = (j0 + s < kp) && (s < smax);
+        if (go) {
+            am = search(s, lnl);
+            go = certain(am, s);
+        }
     }
     const int fin = s & 1;   // buffer holding the state after the last completed step
     stamp(3);

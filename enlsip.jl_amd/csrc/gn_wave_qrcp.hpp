@@ -146,17 +146,23 @@ __device__ __forceinline__ int wave_qrcp(double (&x)[NR], const WaveQrcp& q, con
     double vn2 = vn1, myscale = 0.0;
     mypos = ln;
     int j0 = 0;
-    for (;;) {
+    // single exit at the bottom (the shift of the last block is skipped, not jumped over): with a `break` in the middle the
+    // compiler carries the exit copy and the next-iteration copy of the register rows through the loop (two register sets and
+    // a full copy per block; see k_sb_factor_reg)
+    bool more;
+    do {
         const int rem = q.rows - j0;
 #define GN_WQ_STEP(S) \
     if (j0 + S < q.k) wave_qrcp_substep<NR, S, GRAM>(x, q, j0 + S, rem, ln, mypos, vn1, vn2, myscale);
         GN_WQ_STEP(0) GN_WQ_STEP(1) GN_WQ_STEP(2) GN_WQ_STEP(3)
 #undef GN_WQ_STEP
-        if (j0 + WQ_UNROLL >= q.k) break;
+        more = j0 + WQ_UNROLL < q.k;
+        if (more) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) x[r] = (r + WQ_UNROLL < NR) ? x[(r + WQ_UNROLL < NR) ? r + WQ_UNROLL : r] : 0.0;
-        j0 += WQ_UNROLL;
-    }
+            for (int r = 0; r < NR; ++r) x[r] = (r + WQ_UNROLL < NR) ? x[(r + WQ_UNROLL < NR) ? r + WQ_UNROLL : r] : 0.0;
+            j0 += WQ_UNROLL;
+        }
+    } while (more);
     return j0;
 }
 
@@ -317,16 +323,19 @@ __device__ __forceinline__ int wave_qrcp2(double (&x)[NR], const WaveQrcp2& q, c
     double vn2 = vn1;
     mypos = ln & 31;
     int j0 = 0;
-    for (;;) {
+    bool more;                // single exit at the bottom, as in wave_qrcp
+    do {
 #define GN_WQ2_STEP(S) \
     if (j0 + S < kmax) wave_qrcp2_substep<NR, S>(x, q, j0 + S, ln, mypos, vn1, vn2);
         GN_WQ2_STEP(0) GN_WQ2_STEP(1) GN_WQ2_STEP(2) GN_WQ2_STEP(3)
 #undef GN_WQ2_STEP
-        if (j0 + WQ_UNROLL >= kmax) break;
+        more = j0 + WQ_UNROLL < kmax;
+        if (more) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) x[r] = (r + WQ_UNROLL < NR) ? x[(r + WQ_UNROLL < NR) ? r + WQ_UNROLL : r] : 0.0;
-        j0 += WQ_UNROLL;
-    }
+            for (int r = 0; r < NR; ++r) x[r] = (r + WQ_UNROLL < NR) ? x[(r + WQ_UNROLL < NR) ? r + WQ_UNROLL : r] : 0.0;
+            j0 += WQ_UNROLL;
+        }
+    } while (more);
     return j0;
 }
 
