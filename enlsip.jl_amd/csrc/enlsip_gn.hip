@@ -1103,6 +1103,16 @@ int enlsip_gn_debug_copy_W(enlsip_gn_handle h, int64_t prob, double* out, int64_
     return 0;
 }
 
+#ifdef ENLSIP_SB_STEP_STAMPS
+// diagnostic build only: phase sums of the blocked pivoted QR's step (100 MHz ticks; [8] = steps), reset on read
+extern "C" int enlsip_gn_debug_sb_phase(long long* out) {
+    long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gn::g_sb_phase), sizeof(z)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gn::g_sb_phase), z, sizeof(z)) != hipSuccess) return 1;
+    return 0;
+}
+#endif
+
 int enlsip_gn_get_update_stats(enlsip_gn_handle h, float* avg_ms, int64_t* launches, double* bytes) {
     if (!h) return -1;
     if (avg_ms) *avg_ms = h->upd_avg_ms;

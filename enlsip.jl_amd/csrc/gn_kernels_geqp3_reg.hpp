@@ -28,7 +28,7 @@ __global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
     __shared__ double cvn1[2][64], cvn2[64], taul[64];
     __shared__ int cpos[2][64], colat[64], tslot[64];
     __shared__ double gram[64 * 65];
-    __shared__ double tau_s[2];
+    __shared__ double tau_s[2], beta_s[2];
     const int prob = blockIdx.x + a.prob0;
     const int rows = a.rows, cols = a.cols;
     const int tid = threadIdx.x, ln = lane_id();
@@ -78,38 +78,33 @@ __global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
         asm volatile("" : "+s"(wl));
         const int rd = s & 1, wr = rd ^ 1;
         // pivot: largest partial norm among the active columns, ties -> lowest current position (idamax)
-        double bv = -1.0;
-        int bp = 0x7fffffff, bk = -1;
-        if (cpos[rd][lnl] >= 0) {
-            bv = pivot_key(cvn1[rd][lnl]);
-            bp = cpos[rd][lnl];
-            bk = lnl;
-        }
-        const ArgMax am = wave_argmax(bv, bp, bk);
-        const int ci = am.idx, q = am.pos;
-        if (ci < 0) break;                                 // no active column left (cannot happen for s < kmax; keeps every index below valid)
+        const int cp = cpos[rd][lnl];                      // both words unconditionally: one LDS round trip
+        const double cv = cvn1[rd][lnl];
+        const bool in = cp >= 0;
+        const ArgMax am = wave_argmax(in ? pivot_key(cv) : -1.0, in ? cp : 0x7fffffff, in ? lnl : -1);
+        // s < kmax <= cols: an active column exists, am.idx >= 0.  The clamp keeps every index below valid without a second
+        // loop exit (a `break` here makes the compiler carry two copies of the column block through the loop, see
+        // k_sb_factor_reg)
+        const int ci = am.idx < 0 ? 0 : am.idx, q = am.pos;
+        // the owner only READS its registers here (the retired column takes its reflector / beta in the column loop below);
+        // s < 64: the rows of registers i >= 1 are all below the pivot row, no masks there
         if (wl == ci % NWV) {
 #pragma unroll
             for (int cc = 0; cc < NCW; ++cc) {
                 if (cc == ci / NWV) {
-                    double xn2 = 0.0;
+                    double xn2 = (lnl > s) ? x[cc][0] * x[cc][0] : 0.0;
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i)
-                        if (lnl + 64 * i > s) xn2 += x[cc][i] * x[cc][i];
+                    for (int i = 1; i < RPL; ++i) xn2 += x[cc][i] * x[cc][i];
                     xn2 = wave_allsum(xn2);
                     const double alpha = wave_bcast(x[cc][0], s);      // s < 64: the pivot row sits in register 0
                     const Reflector h = make_reflector(alpha, xn2);
+                    vsh[rd][lnl] = (lnl > s) ? x[cc][0] * h.scale : (lnl == s ? 1.0 : 0.0);
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i) {
-                        const int r = lnl + 64 * i;
-                        const double v = (r > s) ? x[cc][i] * h.scale : (r == s ? 1.0 : 0.0);
-                        vsh[rd][r] = v;
-                        if (r > s) x[cc][i] = v;
-                        if (r == s) x[cc][i] = h.beta;
-                    }
+                    for (int i = 1; i < RPL; ++i) vsh[rd][lnl + 64 * i] = x[cc][i] * h.scale;
                     if (lnl == 0) {
                         taul[s] = h.tau;
                         tau_s[rd] = h.tau;
+                        beta_s[rd] = h.beta;
                         tslot[s] = ci;
                     }
                 }
@@ -119,7 +114,16 @@ __global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
         double v[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) v[i] = vsh[rd][lnl + 64 * i];
-        const double tj = tau_s[rd];
+        // the other LDS words of the step in the same round trip: positions of the wave's columns, the owner's beta, the
+        // norms of the downdate (lane u < 8 <-> column u of this wave)
+        int pkv[NCW];
+#pragma unroll
+        for (int cc = 0; cc < NCW; ++cc) pkv[cc] = cpos[rd][wl + NWV * cc];
+        const double beta_o = beta_s[rd];
+        const int u = lnl & (NCW - 1);
+        const int cu = wl + NWV * u;
+        const double o1_in = cvn1[rd][cu], o2_in = cvn2[cu];
+        const double tj = uniform_f64(tau_s[rd]);
         double dot[NCW], ds[NCW];
 #pragma unroll
         for (int cc = 0; cc < NCW; ++cc) {
@@ -134,8 +138,13 @@ __global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
         for (int cc = 0; cc < NCW; ++cc) {
             const int c = wl + NWV * cc;
             ajc8[cc] = 0.0;
-            if (c == ci) continue;
-            const int pk = cpos[rd][c];
+            if (c == ci) {          // the retired column keeps its reflector below the diagonal, beta on it
+                x[cc][0] = (lnl > s) ? v[0] : (lnl == s ? beta_o : x[cc][0]);
+#pragma unroll
+                for (int i = 1; i < RPL; ++i) x[cc][i] = v[i];
+                continue;
+            }
+            const int pk = uniform_i32(pkv[cc]);
             if (pk >= 0) {
                 if (tj != 0.0) {
                     const double wd = tj * ds[cc];
@@ -149,14 +158,12 @@ __global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
             }
         }
         {   // dlaqp2 norm downdate, lane u < 8 <-> column u of this wave
-            const int u = lnl & (NCW - 1);
-            const int cu = wl + NWV * u;
             const bool mine = (lnl < NCW) && ((actm >> u) & 1u);
             double ajc = 0.0;
 #pragma unroll
             for (int cc = 0; cc < NCW; ++cc) ajc = (u == cc) ? ajc8[cc] : ajc;
-            double o1 = mine ? cvn1[rd][cu] : 0.0;
-            const double o2 = mine ? cvn2[cu] : 1.0;
+            double o1 = mine ? o1_in : 0.0;
+            const double o2 = mine ? o2_in : 1.0;
             bool need = false;
             if (mine && o1 != 0.0) {
                 double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);

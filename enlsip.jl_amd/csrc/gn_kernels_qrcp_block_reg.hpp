@@ -17,6 +17,13 @@
 
 namespace gn {
 
+#ifdef ENLSIP_SB_STEP_STAMPS     // diagnostic build only (tests/sb_step_probe.py): phase times of a pivot step, summed over the steps of wave 0 of problem prob0
+__device__ long long g_sb_phase[16];
+#define SB_PH(i) do { __builtin_amdgcn_sched_barrier(0); if (sb_st) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = wall_clock64(); sb_acc[i] += t_ - sb_t; sb_t = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SB_PH(i) do { } while (0)
+#endif
+
 struct SbRegLds {             // bookkeeping of a block: keys, positions, candidates, the block's Gram / T entries
     double valk[SB_NMAX];
     int posk[SB_NMAX];
@@ -186,6 +193,11 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
         am = search(0, ln);
         go = certain(am, 0);
     }
+#ifdef ENLSIP_SB_STEP_STAMPS
+    const bool sb_st = tid == 0 && prob == a.q.prob0;
+    long long sb_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long sb_t = wall_clock64();
+#endif
     while (go) {
         // opaque per-iteration copies of the lane / wave ids: without them loop-invariant code motion hoists every row
         // mask and LDS address of the unrolled columns out of the loop and spills them
@@ -222,7 +234,9 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
                 }
             }
         }
+        SB_PH(0);       // owner's part (wave 0 owns every 8th pivot)
         __syncthreads();
+        SB_PH(1);       // wait for the owner
         double v[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) v[i] = L.vsh[rd][lnl + 64 * i];
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
         const int u = lnl & (NCW - 1);
         const int ku = wl + NWV * u;
         const double o1_in = L.cvn1[rd][ku], o2_in = L.cvn2[ku];
+        const int pk_u = L.cpos[rd][ku];
         const double tj = uniform_f64(L.tau_s[rd]);
         double dot[NCW], ds[NCW];
 #pragma unroll
@@ -245,41 +260,50 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
             for (int i = 0; i < RPL; ++i) dot[cc] += x[cc][i] * v[i];
         }
         wave_allsumN(dot, ds);
-        // apply the reflector to the active candidates; the dot products with the columns retired earlier in this
-        // block (step a = -1 - cpos - j0 < s) are v_a' v_s, the Gram entries of the T factor
-        double ajc4[NCW];
-        unsigned actm = 0u;
+        SB_PH(2);       // LDS reads, dot products, reduction
+        // apply the reflector to the active candidates, WITHOUT branches per column: a column that is not live (slot beyond K,
+        // the pivot itself, retired earlier) gets the factor 0 — 56 independent FMAs the scheduler can interleave instead of
+        // eight compare / branch / multiply / update / broadcast sequences one behind the other (the column loop was the
+        // longest phase of a step: 0.93 of 3.1 us)
+        double wdv[NCW];
 #pragma unroll
         for (int cc = 0; cc < NCW; ++cc) {
             const int k = wl + NWV * cc;
-            ajc4[cc] = 0.0;
-            if (k >= K) continue;
-            if (k == ci) {          // the retired column keeps its reflector below the diagonal, beta on it
-                x[cc][0] = (lnl > s) ? v[0] : (lnl == s ? beta_o : x[cc][0]);
+            const bool live = (k < K) && (k != ci) && (pkv[cc] >= 0) && (tj != 0.0);
+            wdv[cc] = live ? tj * ds[cc] : 0.0;
+        }
 #pragma unroll
-                for (int i = 1; i < RPL; ++i) x[cc][i] = v[i];
-                continue;
-            }
-            const int pk = uniform_i32(pkv[cc]);
-            if (pk >= 0) {
-                if (tj != 0.0) {
-                    const double wd = tj * ds[cc];
+        for (int cc = 0; cc < NCW; ++cc)
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i) x[cc][i] -= wd * v[i];
+            for (int i = 0; i < RPL; ++i) x[cc][i] -= wdv[cc] * v[i];
+        if (wl == ci % NWV) {       // the retired column keeps its reflector below the diagonal, beta on it
+#pragma unroll
+            for (int cc = 0; cc < NCW; ++cc) {
+                if (cc == ci / NWV) {
+                    x[cc][0] = (lnl > s) ? v[0] : (lnl == s ? beta_o : x[cc][0]);
+#pragma unroll
+                    for (int i = 1; i < RPL; ++i) x[cc][i] = v[i];
                 }
-                ajc4[cc] = row_of(x[cc], s);
-                actm |= 1u << cc;
-            } else {
-                const int aa = (-1 - pk) - j0;
-                if (lnl == 0 && aa >= 0 && aa < 32 && s < 32) L.gram[aa * 33 + s] = ds[cc];
             }
         }
+        // lane u < NCW <-> column u of this wave: its entry in the pivot row (norm downdate) and its dot product — for a column
+        // retired earlier in this block (step aa = -1 - position - j0 < s) that is v_aa' v_s, a Gram entry of the T factor
+        double ajc = 0.0, dsu = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NCW; ++cc) {
+            const double rv = row_of(x[cc], s);
+            ajc = (u == cc) ? rv : ajc;
+            dsu = (u == cc) ? ds[cc] : dsu;
+        }
+        const bool mine_col = (lnl < NCW) && (ku < K) && (ku != ci);
+        if (mine_col && pk_u < 0) {
+            const int aa = (-1 - pk_u) - j0;
+            if (aa >= 0 && aa < 32 && s < 32) L.gram[aa * 33 + s] = dsu;
+        }
+        SB_PH(3);       // column loop: updates, pivot-row entries, Gram entries
         // dlaqp2 norm downdate of the wave's active columns as ONE instruction stream: lane u < NCW <-> column u
         {
-            const bool mine = (lnl < NCW) && ((actm >> u) & 1u);
-            double ajc = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < NCW; ++cc) ajc = (u == cc) ? ajc4[cc] : ajc;
+            const bool mine = mine_col && pk_u >= 0;
             double o1 = mine ? o1_in : 0.0;
             const double o2 = mine ? o2_in : 1.0;
             bool need = false;
@@ -311,6 +335,7 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
             }
             if (mine) L.cvn1[wr][ku] = o1;
         }
+        SB_PH(4);       // norm downdate
         // position bookkeeping (wave 0): pivot at position q <-> column cj that sat at position j.  (Done by the owner's
         // neighbour while the owner builds the reflector instead: no gain, 4.60 -> 4.65 ms per single solve.)
         if (wl == 0) {
@@ -330,14 +355,23 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
                 L.pos_l[pc] = j;
             }
         }
+        SB_PH(5);       // bookkeeping
         __syncthreads();
+        SB_PH(6);       // wait for the slowest wave
         ++s;
         go = (j0 + s < kp) && (s < smax);
         if (go) {
             am = search(s, lnl);
             go = certain(am, s);
         }
+        SB_PH(7);       // pivot search of the next step
     }
+#ifdef ENLSIP_SB_STEP_STAMPS
+    if (sb_st) {
+        for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&g_sb_phase[i], (unsigned long long)sb_acc[i]);
+        atomicAdd((unsigned long long*)&g_sb_phase[8], (unsigned long long)s);
+    }
+#endif
     const int fin = s & 1;   // buffer holding the state after the last completed step
     stamp(3);
     // ---- 4b. T factor (dlarft, forward / columnwise) from the Gram entries gathered during the steps -------------
