@@ -1104,11 +1104,13 @@ int enlsip_gn_debug_copy_W(enlsip_gn_handle h, int64_t prob, double* out, int64_
 }
 
 #ifdef ENLSIP_SB_STEP_STAMPS
-// diagnostic build only: phase sums of the blocked pivoted QR's step (100 MHz ticks; [8] = steps), reset on read
+// diagnostic build only: phase sums of the blocked pivoted QR's step (100 MHz ticks; [8] = steps; [16..23] block-level phases), reset on read; out: 24 words
 extern "C" int enlsip_gn_debug_sb_phase(long long* out) {
     long long z[16] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gn::g_sb_phase), sizeof(z)) != hipSuccess) return 1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(gn::g_sb_phase), z, sizeof(z)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(gn::g_sb_blk), 8 * sizeof(long long)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gn::g_sb_blk), z, 8 * sizeof(long long)) != hipSuccess) return 1;
     return 0;
 }
 #endif

@@ -28,6 +28,11 @@ namespace gn {
 constexpr int SB_KMAX = 64;                  // candidate columns per block (LDS permitting)
 constexpr int SB_NMAX = 1024;
 
+#ifdef ENLSIP_SB_STEP_STAMPS     // diagnostic build only (tests/sb_step_probe.py)
+__device__ long long g_sb_phase[16];
+__device__ long long g_sb_blk[8];      // block-level phases of k_sb_factor_reg, [7] = blocks
+#endif
+
 struct SbInfo {       // per problem, device
     int j0;           // first pivot step of the next block
     int s;            // steps done by the last select/factor launch
@@ -132,6 +137,10 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
     const int nvu = (c.rows_valid + 31) / 32;
     const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;
 
+#ifdef ENLSIP_SB_STEP_STAMPS
+    const bool ub_st = threadIdx.x == 0 && blockIdx.x == 1 && prob == a.q.prob0;
+    long long ub_t0 = wall_clock64();
+#endif
     double acc8[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc8[b] = 0.0;
@@ -150,6 +159,10 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
         if (lr == 0) ssq[w][16 * (b >> 2) + 4 * (b & 3) + lq] = x;
     }
     __syncthreads();
+#ifdef ENLSIP_SB_STEP_STAMPS
+    long long ub_t1 = wall_clock64();
+    if (ub_st) { atomicAdd((unsigned long long*)&g_sb_phase[10], (unsigned long long)(ub_t1 - ub_t0)); atomicAdd((unsigned long long*)&g_sb_phase[12], 1ull); }
+#endif
     if (w != 0 || ln >= 32 || cb0 + ln >= nact) return;
     const int cc = actl[cb0 + ln];
     if (cc >= n2) return;                               // the carried right-hand side has no norm
@@ -177,6 +190,9 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
     }
     vn1[cc] = o1;
     vn2[cc] = o2;
+#ifdef ENLSIP_SB_STEP_STAMPS
+    if (ub_st) atomicAdd((unsigned long long*)&g_sb_phase[11], (unsigned long long)(wall_clock64() - ub_t1));
+#endif
 }
 
 }  // namespace gn

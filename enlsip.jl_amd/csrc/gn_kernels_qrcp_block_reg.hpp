@@ -17,8 +17,7 @@
 
 namespace gn {
 
-#ifdef ENLSIP_SB_STEP_STAMPS     // diagnostic build only (tests/sb_step_probe.py): phase times of a pivot step, summed over the steps of wave 0 of problem prob0
-__device__ long long g_sb_phase[16];
+#ifdef ENLSIP_SB_STEP_STAMPS     // diagnostic build only (tests/sb_step_probe.py): phase times of a pivot step, summed over the steps of wave 0 of problem prob0 (g_sb_phase: gn_kernels_qrcp_block.hpp)
 #define SB_PH(i) do { __builtin_amdgcn_sched_barrier(0); if (sb_st) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = wall_clock64(); sb_acc[i] += t_ - sb_t; sb_t = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SB_PH(i) do { } while (0)
@@ -78,9 +77,20 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
     int* colat = a.q.colat + prob * 2 * a.q.sI;
     const double tol3z = 1.4901161193847656e-08;
 
+#ifdef ENLSIP_SB_STEP_STAMPS
+    long long bl_t = wall_clock64();
+    auto stamp = [&](int i) {        // block-level phases: time since the previous stamp -> g_sb_blk[i]
+        if (tid == 0 && prob == a.q.prob0) {
+            const long long t_ = wall_clock64();
+            atomicAdd((unsigned long long*)&g_sb_blk[i], (unsigned long long)(t_ - bl_t));
+            bl_t = t_;
+        }
+    };
+#else
     auto stamp = [&](int i) {
         if (a.dbg && tid == 0 && prob == a.q.prob0) a.dbg[a.blkid * 8 + i] = (long long)__builtin_amdgcn_s_memrealtime();
     };
+#endif
     stamp(0);
     // ---- 1. keys of the trailing columns --------------------------------------------------------
     for (int c = tid; c < n2; c += NT) {
@@ -115,8 +125,13 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
             sc[e] = in ? e : -1;
         }
         __syncthreads();
+        // P / 2 <= NT: a thread handles one pair per pass, and in the passes with partner distance jx <= 64 the pairs of wave w
+        // lie in elements [128 w, 128 w + 128) — wave-local, no workgroup barrier.  Only the passes with jx >= 128 (three of
+        // the 45 at P = 512) exchange data between waves: barriers around those only.
+        static_assert(NT >= SB_NMAX / 2, "one pair per thread and pass");
         for (int kk = 2; kk <= P; kk <<= 1) {
             for (int jx = kk >> 1; jx > 0; jx >>= 1) {
+                if (jx >= 128) __syncthreads();
                 for (int t = tid; t < (P >> 1); t += NT) {
                     const int i = ((t & ~(jx - 1)) << 1) | (t & (jx - 1));
                     const int l = i | jx;
@@ -131,9 +146,11 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
                         sc[i] = cb; sc[l] = ca;
                     }
                 }
-                __syncthreads();
+                if (jx >= 128) __syncthreads();
+                else wave_mem_sync();
             }
         }
+        __syncthreads();
         for (int r = tid; r < n2; r += NT) {
             const int c = sc[r];
             const int p = sp[r];
@@ -194,7 +211,10 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
         go = certain(am, 0);
     }
 #ifdef ENLSIP_SB_STEP_STAMPS
-    const bool sb_st = tid == 0 && prob == a.q.prob0;
+#ifndef ENLSIP_SB_STAMP_WAVE
+#define ENLSIP_SB_STAMP_WAVE 0
+#endif
+    const bool sb_st = tid == 64 * ENLSIP_SB_STAMP_WAVE && prob == a.q.prob0;
     long long sb_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long sb_t = wall_clock64();
 #endif
@@ -336,8 +356,10 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
             if (mine) L.cvn1[wr][ku] = o1;
         }
         SB_PH(4);       // norm downdate
-        // position bookkeeping (wave 0): pivot at position q <-> column cj that sat at position j.  (Done by the owner's
-        // neighbour while the owner builds the reflector instead: no gain, 4.60 -> 4.65 ms per single solve.)
+        // position bookkeeping (wave 0): pivot at position q <-> column cj that sat at position j.  Wave 0 has the time: the two
+        // waves of a SIMD share its issue slots and the older one (waves 0..3) has priority, so waves 4..7 reach the barrier
+        // ~0.5 us later anyway (phase stamps per wave, tests/sb_step_probe.py); done by the owner's neighbour under the owner's
+        // reflector construction instead, the step takes the same time.
         if (wl == 0) {
             const int pc = L.ccol[ci];
             const int cj = L.colat_l[j];
@@ -386,9 +408,10 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
             for (int b = 0; b < 32; ++b) {
                 const bool on = b < s;
                 const double tb = on ? L.taul[L.tslot[on ? b : 0]] : 0.0;
-                double acc = 0.0;
+                double ac[4] = {0.0, 0.0, 0.0, 0.0};         // four chains: the sum is latency bound, not FMA bound
 #pragma unroll
-                for (int l = 0; l < b; ++l) acc += trow[l] * L.gram[l * 33 + b];
+                for (int l = 0; l < b; ++l) ac[l & 3] += trow[l] * L.gram[l * 33 + b];
+                const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
                 const double tv = on ? ((ln == b) ? tb : ((ln < b) ? -tb * acc : 0.0)) : 0.0;
                 trow[b] = tv;
                 T[ln + b * 32] = tv;
@@ -461,6 +484,10 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
         SbInfo o = {j0 + s, s, a.blkid, j0, nact, {0, 0, 0}};
         *info = o;
     }
+#ifdef ENLSIP_SB_STEP_STAMPS
+    stamp(5);
+    if (tid == 0 && prob == a.q.prob0) atomicAdd((unsigned long long*)&g_sb_blk[7], 1ull);
+#endif
 }
 
 }  // namespace gn

@@ -14,7 +14,7 @@ J, rx, At, cx = wl.make_batch(0, B, m, n, t, dev)
 p = torch.empty((B, n), dtype=torch.float64, device=dev)
 s = GNSolver(device=0)
 lib = C.CDLL(str(_lib.LIB_PATH))
-out = (C.c_longlong * 16)()
+out = (C.c_longlong * 24)()
 names = ["owner's part (1/8 of the steps)", "wait for the owner", "LDS reads + dots + reduction", "column loop", "norm downdate",
          "bookkeeping", "wait for the slowest wave", "next pivot search"]
 for rep in range(3):
@@ -26,3 +26,11 @@ tot = sum(out[i] for i in range(8))
 print(f"batch {B}: {steps} steps, {tot / steps * 10:.0f} ns per step (wave 0 of problem 0)")
 for i, nm in enumerate(names):
     print(f"  {out[i] / steps * 10:7.0f} ns  {nm}")
+if out[12]:
+    print(f"k_sb_update_blk, workgroup 1 of problem 0, mean over {out[12]} launches: block update {out[10] / out[12] * 10:.0f} ns, norm downdate tail {out[11] / out[12] * 10:.0f} ns")
+nb = out[23]
+if nb:
+    bn = ["early exits + keys", "ranking sort + candidate list", "candidates -> registers", "pivot steps", "T factor", "write back + active list"]
+    print(f"k_sb_factor_reg per block (mean over {nb} blocks of problem 0, all forms):")
+    for i, nm in enumerate(bn):
+        print(f"  {out[16 + i] / nb * 10:8.0f} ns  {nm}")
