@@ -195,16 +195,11 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
             bc = cd.col;
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(bv, off, WAVE);
-        const int op = __shfl_xor(bp, off, WAVE);
-        const int oc = __shfl_xor(bc, off, WAVE);
-        if (qd_better(ov, op, bv, bp)) {
-            bv = ov;
-            bp = op;
-            bc = oc;
-        }
+    {   // DPP butterflies + readlanes (wave_argmax: same (value, position) order as qd_better) instead of six ds_bpermute rounds
+        const ArgMax am = wave_argmax(bv, bp, bc);
+        bv = am.val;
+        bp = am.pos;
+        bc = am.idx;
     }
     if (bc < 0) return;        // no candidate (cannot happen while unchosen columns exist: NaN norms rank as +inf); every
                                // workgroup takes the same decision, so nobody indexes with -1
