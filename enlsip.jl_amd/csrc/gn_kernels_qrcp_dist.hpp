@@ -306,18 +306,22 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
         if (k < n2) colat_new[k] = (k == j) ? p : ((k == q) ? cj : colat_old[k]);
     }
     __syncthreads();
-    // (e) candidate for the next step
-    if (threadIdx.x == 0) {
-        double cv = -1.0;
-        int cp = 0x7fffffff, cc = -1;
-        for (int s = 0; s < QD_CPW; ++s)
-            if (qd_better(cval[s], cpos[s], cv, cp)) {
-                cv = cval[s];
-                cp = cpos[s];
-                cc = g * QD_CPW + s;
-            }
-        QdCand cd = {cv, cp, cc};
-        cand_new[g] = cd;
+    // (e) candidate for the next step: lanes 0..7 of wave 0 hold the eight slots, three DPP levels inside the group of 8 (the
+    // kernel cannot end before this: a serial loop of one thread over the slots cost eight dependent LDS round trips per step)
+    if (w == 0) {
+        static_assert(QD_CPW == 8, "eight slots <-> lanes 0..7");
+        const bool in = ln < QD_CPW;
+        const double sv = cval[ln & (QD_CPW - 1)];
+        const int sp = cpos[ln & (QD_CPW - 1)];
+        const bool has = in && qd_better(sv, sp, -1.0, 0x7fffffff);          // an empty slot never wins (as in the serial loop)
+        ArgMax am = {has ? sv : -1.0, has ? sp : 0x7fffffff, has ? g * QD_CPW + ln : -1};
+        am_step<0xB1>(am);     // quad_perm [1,0,3,2]
+        am_step<0x4E>(am);     // quad_perm [2,3,0,1]
+        am_step<0x141>(am);    // row_half_mirror: the other quad of the group of 8
+        if (ln == 0) {
+            QdCand cd = {am.val, am.pos, am.idx};
+            cand_new[g] = cd;
+        }
     }
 }
 
