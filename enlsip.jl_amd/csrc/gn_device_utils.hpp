@@ -156,6 +156,24 @@ __device__ __forceinline__ int dpp_i32(int x) {
     return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
 }
 
+// The dword of lane (l ^ JX), JX = 1 .. 32, without LDS: DPP inside the rows of 16 lanes, permlane swaps across them.
+template <int JX>
+__device__ __forceinline__ int lane_xor_i32(int x, int ln) {
+    if constexpr (JX == 1) return dpp_i32<0xB1>(x);            // quad_perm [1,0,3,2]
+    else if constexpr (JX == 2) return dpp_i32<0x4E>(x);       // quad_perm [2,3,0,1]
+    else if constexpr (JX == 4) {                              // row_ror:12 brings lane i + 4, row_ror:4 lane i - 4
+        const int up = dpp_i32<0x12C>(x), dn = dpp_i32<0x124>(x);
+        return (ln & 4) ? dn : up;
+    } else if constexpr (JX == 8) return dpp_i32<0x128>(x);    // row_ror:8
+    else if constexpr (JX == 16) {
+        const auto a = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);   // {r0,r0,r2,r2} / {r1,r1,r3,r3}
+        return (ln & 16) ? (int)a[0] : (int)a[1];
+    } else {
+        const auto a = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);   // {lo,lo} / {hi,hi}
+        return (ln & 32) ? (int)a[0] : (int)a[1];
+    }
+}
+
 // Pivot key of a partial column norm: a NaN norm (NaN / Inf in the input) ranks as +infinity, so that a pivot search always
 // returns one of its candidates — with plain comparisons a NaN never wins and the search comes back empty (index -1), which
 // the callers would use as a column index.

@@ -112,7 +112,76 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
     __syncthreads();
     // ---- 2. order the trailing columns by (norm desc, position asc): bitonic sort of (norm, position, column) in
     // LDS (the Gram / T images are free now); rank r < K = candidate slot r, rank K = best outside column = the bound
-    {
+    if (n2 <= 512 && NT == 512) {
+        // Register form (at most 512 columns, one element per thread): a bitonic network over 512 records (norm, position << 16 |
+        // column) — the packed word makes the order strict and total, so every element can decide for itself whether it keeps
+        // its record or takes its partner's.  Partners at distance < 64 are lanes of the same wave (DPP / permlane swaps: no
+        // memory, no barrier — 39 of the 45 passes), partners at distance >= 64 go through two alternating LDS images with one
+        // barrier per pass.  Fully unrolled: the partner distance of a pass is a constant.  Per block (C2, phase stamps): 4.2 us
+        // against 13.3 us for the LDS form below, which pays an LDS round trip per pass (with ds_bpermute exchanges 4.9 us; with
+        // the loops left rolled 7.7 us, and 11.3 us with the DPP exchanges behind a run-time switch).
+        double* xv = L.gram;                                                       // 2 x 512 doubles
+        unsigned* xp = reinterpret_cast<unsigned*>(L.gram + 1024);                 // 2 x 512 words
+        const int e = tid;
+        const bool real = e < n2;
+        double v = real ? L.valk[e] : -2.0;
+        const int p0 = real ? L.posk[e] : 0x7fffffff;
+        unsigned pc = ((unsigned)(p0 > 0xFFFF ? 0xFFFF : p0) << 16) | (unsigned)e;
+        int xb = 0;
+#pragma unroll
+        for (int kk = 2; kk <= 512; kk <<= 1) {
+            const bool up = (e & kk) == 0;                  // better-first in this half
+#pragma unroll
+            for (int jx = kk >> 1; jx > 0; jx >>= 1) {
+                double pv;
+                unsigned ppc;
+                if (jx >= 64) {
+                    xv[512 * xb + e] = v;
+                    xp[512 * xb + e] = pc;
+                    __syncthreads();
+                    pv = xv[512 * xb + (e ^ jx)];
+                    ppc = xp[512 * xb + (e ^ jx)];
+                    xb ^= 1;
+                } else {
+                    int lo = __double2loint(v), hi = __double2hiint(v), pw = (int)pc;
+                    switch (jx) {                           // a constant after unrolling
+#define GN_SB_X(J) case J: lo = lane_xor_i32<J>(lo, ln); hi = lane_xor_i32<J>(hi, ln); pw = lane_xor_i32<J>(pw, ln); break;
+                        GN_SB_X(1) GN_SB_X(2) GN_SB_X(4) GN_SB_X(8) GN_SB_X(16)
+                        default: lo = lane_xor_i32<32>(lo, ln); hi = lane_xor_i32<32>(hi, ln); pw = lane_xor_i32<32>(pw, ln); break;
+#undef GN_SB_X
+                    }
+                    ppc = (unsigned)pw;
+                    pv = __hiloint2double(hi, lo);
+                }
+                const bool partner_better = pv > v || (pv == v && ppc < pc);
+                const bool lower = (e & jx) == 0;            // this element is the first of its pair
+                const bool take = lower ? (partner_better == up) : (partner_better != up);
+                if (take) {
+                    v = pv;
+                    pc = ppc;
+                }
+            }
+        }
+        // thread r holds the record of rank r
+        {
+            const int r = tid;
+            const int c = (int)(pc & 0xFFFFu);
+            const int p = (int)(pc >> 16);
+            if (c < n2 && p != 0xFFFF) {                    // not padding, a trailing column
+                L.rankl[c] = r;
+                if (r < K) {
+                    L.ccol[r] = c;
+                    L.cpos[0][r] = p;
+                    L.cvn1[0][r] = v;
+                    L.cvn2[r] = vn2[c];
+                    a.inblk[prob * a.sIn + c] = a.blkid;
+                } else if (r == K) {
+                    L.bval = v;
+                    L.bpos = p;
+                }
+            }
+        }
+    } else {
         int P = 64;
         while (P < n2) P <<= 1;                            // <= 1024
         double* sv = L.gram;                               // 1024 doubles
