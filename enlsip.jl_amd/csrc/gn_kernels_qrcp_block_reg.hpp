@@ -35,6 +35,7 @@ struct SbRegLds {             // bookkeeping of a block: keys, positions, candid
     double gram[32 * 33];
     double tmat[32 * 33];
     int tslot[32];
+    double taustep[32];       // tau of the block's steps, by step (the T factor reads them without the detour over tslot)
     double vsh[2][512];       // reflector broadcast, double-buffered by step parity
     double tau_s[2];
     int wtot[16];
@@ -318,7 +319,10 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
                         L.taul[ci] = h.tau;
                         L.betal[ci] = h.beta;
                         L.tau_s[rd] = h.tau;
-                        if (s < 32) L.tslot[s] = ci;
+                        if (s < 32) {
+                            L.tslot[s] = ci;
+                            L.taustep[s] = h.tau;
+                        }
                     }
                 }
             }
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
 #pragma unroll
             for (int b = 0; b < 32; ++b) {
                 const bool on = b < s;
-                const double tb = on ? L.taul[L.tslot[on ? b : 0]] : 0.0;
+                const double tb = on ? L.taustep[b] : 0.0;
                 double ac[4] = {0.0, 0.0, 0.0, 0.0};         // four chains: the sum is latency bound, not FMA bound
 #pragma unroll
                 for (int l = 0; l < b; ++l) ac[l & 3] += trow[l] * L.gram[l * 33 + b];
