@@ -287,8 +287,19 @@ static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
     // one-tile problems of at most 256 rows: 4 waves x 8 columns issue ~20 % fewer instructions per step than 8 x 4
     // (measured on C5: panel stage 0.63 -> 0.57 ms); everywhere else the 8-wave form wins (a 16-wave form: 8.1 -> 11.2 ms)
     if (h->plan.m > 256) {
-        if (h->plan.RPL == 8) hipLaunchKernelGGL((k_caqr_factor<8, 8>), grid, dim3(512), 0, h->stream, a);
-        else hipLaunchKernelGGL((k_caqr_factor<4, 8>), grid, dim3(512), 0, h->stream, a);
+        // a tree level with ONE node of few blocks (the top of a tree; C2's first-panel trees: 8 blocks) needs only
+        // ceil(blocks / 2) registers per lane and column: the smaller forms issue fewer multiply-adds per step on rows that hold
+        // nothing (the geometry of a node is the same in every form: slot ln + 64 i = block (ln >> 5) + 2 i)
+        int rpl = h->plan.RPL;
+        if (a.level > 0 && groups == 1) {
+            const int need = (a.nblocks + 1) / 2;
+            const int fit = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 8));
+            if (fit < rpl) rpl = fit;
+        }
+        if (rpl == 8) hipLaunchKernelGGL((k_caqr_factor<8, 8>), grid, dim3(512), 0, h->stream, a);
+        else if (rpl == 4) hipLaunchKernelGGL((k_caqr_factor<4, 8>), grid, dim3(512), 0, h->stream, a);
+        else if (rpl == 2) hipLaunchKernelGGL((k_caqr_factor<2, 8>), grid, dim3(512), 0, h->stream, a);
+        else hipLaunchKernelGGL((k_caqr_factor<1, 8>), grid, dim3(512), 0, h->stream, a);
     } else {
         if (h->plan.RPL == 8) hipLaunchKernelGGL((k_caqr_factor<8, 4>), grid, dim3(256), 0, h->stream, a);
         else hipLaunchKernelGGL((k_caqr_factor<4, 4>), grid, dim3(256), 0, h->stream, a);
