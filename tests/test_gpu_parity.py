@@ -253,6 +253,9 @@ def test_pipelined_device_batch_matches_oracle(shape, monkeypatch):
     ("rankdefJ", 900, 260, 35),      # rank-deficient J2 through the blocked pivoted QR
     ("graded", 1200, 280, 30),       # graded singular values: norm-downdate recomputations
     ("full", 300, 330, 40),          # m < n2: kp = m
+    ("full", 450, 520, 8),           # n2 = 512: the register form of the ranking sort at its limit (one record per thread)
+    ("full", 450, 521, 8),           # n2 = 513: the LDS form of the ranking sort (P = 1024)
+    ("full", 400, 700, 20),          # n2 = 680, kp = 400: the LDS form well inside its range
     ("full", 513, 140, 0),           # no constraints, one row past a tile boundary
     ("full", 1300, 600, 8),          # kp = 592 > 512 rows: launch-per-step pivoted QR (k_qd_*)
     ("rankdefJ", 1100, 560, 6),      # the same path with a rank-deficient J2
