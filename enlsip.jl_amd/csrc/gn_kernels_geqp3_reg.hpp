@@ -123,6 +123,7 @@ __global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
         const int u = lnl & (NCW - 1);
         const int cu = wl + NWV * u;
         const double o1_in = cvn1[rd][cu], o2_in = cvn2[cu];
+        const int pk_u = cpos[rd][cu];
         const double tj = uniform_f64(tau_s[rd]);
         double dot[NCW], ds[NCW];
 #pragma unroll
@@ -132,36 +133,41 @@ __global__ __launch_bounds__(512) void k_geqp3_reg(Geqp3RegArgs a) {
             for (int i = 0; i < RPL; ++i) dot[cc] += x[cc][i] * v[i];
         }
         wave_allsum8(dot, ds);
-        double ajc8[NCW];
-        unsigned actm = 0u;
+        // every column without a branch: factor 0 for the pivot itself, retired columns and slots without a column (as in
+        // k_sb_factor_reg: 64 independent multiply-adds instead of eight compare / branch / update / broadcast sequences)
+        double wdv[NCW];
 #pragma unroll
         for (int cc = 0; cc < NCW; ++cc) {
             const int c = wl + NWV * cc;
-            ajc8[cc] = 0.0;
-            if (c == ci) {          // the retired column keeps its reflector below the diagonal, beta on it
-                x[cc][0] = (lnl > s) ? v[0] : (lnl == s ? beta_o : x[cc][0]);
+            const bool live = (c != ci) && (pkv[cc] >= 0) && (tj != 0.0);
+            wdv[cc] = live ? tj * ds[cc] : 0.0;
+        }
 #pragma unroll
-                for (int i = 1; i < RPL; ++i) x[cc][i] = v[i];
-                continue;
-            }
-            const int pk = uniform_i32(pkv[cc]);
-            if (pk >= 0) {
-                if (tj != 0.0) {
-                    const double wd = tj * ds[cc];
+        for (int cc = 0; cc < NCW; ++cc)
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i) x[cc][i] -= wd * v[i];
+            for (int i = 0; i < RPL; ++i) x[cc][i] -= wdv[cc] * v[i];
+        if (wl == ci % NWV) {       // the retired column keeps its reflector below the diagonal, beta on it
+#pragma unroll
+            for (int cc = 0; cc < NCW; ++cc) {
+                if (cc == ci / NWV) {
+                    x[cc][0] = (lnl > s) ? v[0] : (lnl == s ? beta_o : x[cc][0]);
+#pragma unroll
+                    for (int i = 1; i < RPL; ++i) x[cc][i] = v[i];
                 }
-                ajc8[cc] = wave_bcast(x[cc][0], s);
-                actm |= 1u << cc;
-            } else if (pk > -1000) {
-                if (lnl == 0) gram[(-1 - pk) * 65 + s] = ds[cc];      // v_a' v_s, a = step that retired this column
             }
         }
-        {   // dlaqp2 norm downdate, lane u < 8 <-> column u of this wave
-            const bool mine = (lnl < NCW) && ((actm >> u) & 1u);
-            double ajc = 0.0;
+        // lane u < 8 <-> column u of this wave: its entry in the pivot row and its dot product (Gram entry of a retired column)
+        double ajc = 0.0, dsu = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < NCW; ++cc) ajc = (u == cc) ? ajc8[cc] : ajc;
+        for (int cc = 0; cc < NCW; ++cc) {
+            const double rv = wave_bcast(x[cc][0], s);
+            ajc = (u == cc) ? rv : ajc;
+            dsu = (u == cc) ? ds[cc] : dsu;
+        }
+        const bool mine_col = (lnl < NCW) && (cu != ci);
+        if (mine_col && pk_u < 0 && pk_u > -1000) gram[(-1 - pk_u) * 65 + s] = dsu;      // v_a' v_s, a = step that retired this column
+        {   // dlaqp2 norm downdate, lane u < 8 <-> column u of this wave
+            const bool mine = mine_col && pk_u >= 0;
             double o1 = mine ? o1_in : 0.0;
             const double o2 = mine ? o2_in : 1.0;
             bool need = false;
