@@ -361,6 +361,26 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         }
         return 0;
     };
+    // every other trailing-update launch (tree levels, the second panel's own columns): timed too, booked under
+    // ENLSIP_GN_STAGE_UPDATE and reported by enlsip_gn_get_update_totals
+    auto other = [&](hipStream_t st, auto&& launch) -> int {
+        hipEvent_t e1 = nullptr;
+        if (h->profiling) {
+            if (h->oth_used + 2 > h->oth_ev.size()) {
+                for (int q = 0; q < 2; ++q) {
+                    hipEvent_t e;
+                    GN_HIP(hipEventCreate(&e));
+                    h->oth_ev.push_back(e);
+                }
+            }
+            hipEvent_t e0 = h->oth_ev[h->oth_used++];
+            e1 = h->oth_ev[h->oth_used++];
+            GN_HIP(hipEventRecord(e0, st));
+        }
+        launch();
+        if (e1) GN_HIP(hipEventRecord(e1, st));
+        return 0;
+    };
     auto btrail = [&](int k, double ncols) { const double mk = mpad - (double)k * PB; return 8.0 * (2.0 * mk * ncols + mk * PB + PB * PB); };
     // the MFMA update of every trailing column of the window; with the J2 columns filling whole 32-column blocks the carried
     // right-hand side (the 32 j + 1-th column: every panel of C2) would take a block of its own: it gets its own routine as the
@@ -411,6 +431,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         if (h->debug_maxpan >= 0 && k >= h->debug_maxpan) break;   // ENLSIP_GN_DEBUG_MAXPAN: stop the sweep (debugging aid)
         const int bwk = std::min(PB, kp_launch - k * PB);
         const int ntrail = n2_launch + 1 - (k * PB + bwk);  // trailing columns incl. the augmented one
+        if (h->profiling && ntrail > 0) h->upd_all_bytes += (double)P.batch * btrail(k, ntrail);   // every column right of the panel
         if (P.pair && use_mfma && !(k & 1) && k + 1 < npan) {
             // ---- panel pair (k, k + 1): tiles shared, ONE pass over the far trailing columns for both (gn_kernels_caqr.hpp) ----
             const int kb = k + 1;
@@ -418,12 +439,20 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             const auto& LB = P.panels[kb].levels;
             const int bwb = std::min(PB, kp_launch - kb * PB);
             const int nfar = ntrail - bwb;                   // columns beyond the pair, incl. the augmented one (>= 1)
+            if (h->profiling && nfar > 0) h->upd_all_bytes += (double)P.batch * btrail(kb, nfar);
+            // Grid of the launches over the far window (win = 2).  A problem whose J2 ends inside the pair has bwb fewer pair
+            // columns and as many more far columns than the launch shape says, so with mixed widths the grid spans ntrail and the
+            // column block past a problem's last column exits at once.  In a uniform batch that block is ALWAYS empty — and not
+            // free: with 8 tiles in x (= the 8 XCDs) a grid whose y extent is a multiple of 4 hands the empty and the light
+            // (right-hand side) block of every problem to the same two of an XCD's four dispatch queues, measured 5-20 % on the
+            // far launches of pairs 1, 3, 5 of a C2 step (profiles/r4_notes.md).  The exact grid has an odd y extent.
+            const int far_grid = mixed ? ntrail : nfar;
             auto live = [&](int st) { return h->debug_stage < 0 || st <= h->debug_stage; };   // ENLSIP_GN_DEBUG_STAGE (debugging aid)
             if (live(0)) {   // level 0 of the first panel, applied to the second panel's columns only
                 CaqrArgs a = caqr_args(h, k, LA[0]);
                 launch_factor(h, a, LA[0].groups);
                 a.win = 1;
-                launch_update_v4(h->plan.RPL, a, LA[0].groups, bwb, (int)P.batch, h->stream);
+                if (int rc = other(h->stream, [&] { launch_update_v4(h->plan.RPL, a, LA[0].groups, bwb, (int)P.batch, h->stream); })) return rc;
             }
             if (live(1)) {   // level 0 of the second panel: the same tiles without their first 32 rows
                 CaqrArgs a = caqr_args(h, kb, LB[0]);
@@ -433,7 +462,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
                 CaqrArgs a = caqr_args(h, k, LA[li]);
                 launch_factor(h, a, LA[li].groups);
                 a.win = 1;
-                launch_update_v4(h->plan.RPL, a, LA[li].groups, bwb, (int)P.batch, h->stream);
+                if (int rc = other(h->stream, [&] { launch_update_v4(h->plan.RPL, a, LA[li].groups, bwb, (int)P.batch, h->stream); })) return rc;
             }
             for (size_t li = 1; li < LB.size() && live(3); ++li) {      // tree of the second panel
                 CaqrArgs a = caqr_args(h, kb, LB[li]);
@@ -459,19 +488,19 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
                     const bool has_rhs = (sub0 + ncw == nfar);
                     const double by = btrail(k, ncw) + btrail(kb, ncw);
                     int rc = timed(by, st, [&] {
-                        if (has_rhs) update_l0(a, LA[0], ncw, ncw + (ntrail - nfar), st);
+                        if (has_rhs) update_l0(a, LA[0], ncw, ncw, st);          // look-ahead sweeps are uniform (la implies !mixed)
                         else launch_update_v4(h->plan.RPL, a, LA[0].groups, ncw, (int)P.batch, st);
                     });
                     if (rc) return rc;
                     for (size_t li = 1; li < LA.size(); ++li) {
                         CaqrArgs t = caqr_args(h, k, LA[li]);
                         t.win = 2; t.sub0 = sub0; t.subn = subn;
-                        launch_update_v4(h->plan.RPL, t, LA[li].groups, ncw + (ntrail - nfar), (int)P.batch, st);
+                        if (int rc2 = other(st, [&] { launch_update_v4(h->plan.RPL, t, LA[li].groups, ncw, (int)P.batch, st); })) return rc2;
                     }
                     for (size_t li = 1; li < LB.size(); ++li) {
                         CaqrArgs t = caqr_args(h, kb, LB[li]);
                         t.sub0 = sub0; t.subn = subn;
-                        launch_update_v4(h->plan.RPL, t, LB[li].groups, ncw, (int)P.batch, st);
+                        if (int rc2 = other(st, [&] { launch_update_v4(h->plan.RPL, t, LB[li].groups, ncw, (int)P.batch, st); })) return rc2;
                     }
                     return 0;
                 };
@@ -496,7 +525,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             } else {
                 CaqrArgs a = caqr_args(h, k, LA[0]);
                 a.win = 2; a.pair = 1; a.tOff2 = LB[0].tOff;
-                int rc = timed(btrail(k, nfar) + btrail(kb, nfar), h->stream, [&] { update_l0(a, LA[0], nfar, ntrail, h->stream); });
+                int rc = timed(btrail(k, nfar) + btrail(kb, nfar), h->stream, [&] { update_l0(a, LA[0], nfar, far_grid, h->stream); });
                 if (rc) return rc;
                 if (mixed) {        // problems whose J2 ends before the second panel: the first panel alone, every trailing column
                     a.pair = 2;
@@ -506,11 +535,11 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             for (size_t li = 1; li < LA.size() && live(6); ++li) {
                 CaqrArgs a = caqr_args(h, k, LA[li]);
                 a.win = 2;
-                launch_update_v4(h->plan.RPL, a, LA[li].groups, ntrail, (int)P.batch, h->stream);
+                if (int rc = other(h->stream, [&] { launch_update_v4(h->plan.RPL, a, LA[li].groups, far_grid, (int)P.batch, h->stream); })) return rc;
             }
             for (size_t li = 1; li < LB.size() && live(7); ++li) {
                 CaqrArgs a = caqr_args(h, kb, LB[li]);
-                launch_update_v4(h->plan.RPL, a, LB[li].groups, nfar, (int)P.batch, h->stream);
+                if (int rc = other(h->stream, [&] { launch_update_v4(h->plan.RPL, a, LB[li].groups, nfar, (int)P.batch, h->stream); })) return rc;
             }
             k += 2;
             continue;
@@ -527,7 +556,9 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
                 if (use_mfma && L.level == 0) {
                     int rc = timed(btrail(k, ntrail), h->stream, [&] { update_l0(a, L, ntrail, ntrail, h->stream); });
                     if (rc) return rc;
-                } else if (use_mfma) launch_update_v4(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream);
+                } else if (use_mfma) {
+                    if (int rc = other(h->stream, [&] { launch_update_v4(h->plan.RPL, a, L.groups, ntrail, (int)P.batch, h->stream); })) return rc;
+                }
                 else launch_update_refl(h, a, L.groups, ntrail);
             }
         }
@@ -784,6 +815,8 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         h->upd_used = 0;
         h->upd_bytes = 0.0;
         h->upd_launch_bytes.clear();
+        h->oth_used = 0;
+        h->upd_all_bytes = 0.0;
     }
     auto mark = [&](int i) { if (h->profiling) (void)hipEventRecord(h->ev[i], s); };
 
@@ -896,8 +929,18 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         }
         h->upd_launches = (long long)(h->upd_used / 2);
         h->upd_avg_ms = h->upd_launches ? upd / (float)h->upd_launches : 0.f;
-        h->stage_ms[ENLSIP_GN_STAGE_UPDATE] = upd;
-        h->stage_ms[ENLSIP_GN_STAGE_PANEL] = ms - upd;
+        // every trailing-update launch of the sweep is "update" (far level-0 passes AND tree levels / second-panel columns);
+        // "panel" = the factorisations (and whatever else the sweep launches)
+        float oth = 0.f;
+        for (size_t i = 0; i + 1 < h->oth_used; i += 2) {
+            float u;
+            GN_HIP(hipEventElapsedTime(&u, h->oth_ev[i], h->oth_ev[i + 1]));
+            oth += u;
+        }
+        h->oth_ms = oth;
+        h->oth_launches = (long long)(h->oth_used / 2);
+        h->stage_ms[ENLSIP_GN_STAGE_UPDATE] = upd + oth;
+        h->stage_ms[ENLSIP_GN_STAGE_PANEL] = ms - upd - oth;
         GN_HIP(hipEventElapsedTime(&ms, h->ev[3], h->ev[4])); h->stage_ms[ENLSIP_GN_STAGE_PIVOT] = ms;
         GN_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[4])); h->stage_ms[ENLSIP_GN_STAGE_TOTAL] = ms;
         (void)map;
@@ -1010,6 +1053,7 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->ev_ready)
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->upd_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->oth_ev) (void)hipEventDestroy(e);
     if (h->sub) (void)enlsip_gn_destroy(h->sub);
     if (h->child) (void)enlsip_gn_destroy(h->child);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1131,6 +1175,24 @@ int enlsip_gn_get_update_stats(enlsip_gn_handle h, float* avg_ms, int64_t* launc
     if (avg_ms) *avg_ms = h->upd_avg_ms;
     if (launches) *launches = h->upd_launches;
     if (bytes) *bytes = h->upd_bytes;
+    return 0;
+}
+
+int enlsip_gn_get_launch_plan(enlsip_gn_handle h, int64_t* pipeline_split, int* panel_pairs, int64_t* tile_rows) {
+    if (!h) return -1;
+    if (!h->have_plan) { h->err = "no solve on this handle yet"; return -1; }
+    if (pipeline_split) *pipeline_split = h->split;
+    if (panel_pairs) *panel_pairs = h->plan.pair ? 1 : 0;
+    if (tile_rows) *tile_rows = 64LL * h->plan.RPL;
+    return 0;
+}
+
+int enlsip_gn_get_update_totals(enlsip_gn_handle h, float* far_ms, float* other_ms, int64_t* other_launches, double* all_panels_bytes) {
+    if (!h) return -1;
+    if (far_ms) *far_ms = h->upd_avg_ms * (float)h->upd_launches;
+    if (other_ms) *other_ms = h->oth_ms;
+    if (other_launches) *other_launches = h->oth_launches;
+    if (all_panels_bytes) *all_panels_bytes = h->upd_all_bytes;
     return 0;
 }
 

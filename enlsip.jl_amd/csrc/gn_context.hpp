@@ -139,4 +139,10 @@ struct enlsip_gn_context {
     std::vector<float> upd_launch_ms;
     float upd_avg_ms = 0.f;
     long long upd_launches = 0;
+    // every OTHER trailing-update launch of the sweep (tree levels, a pair's second-panel columns): event pairs, summed time
+    std::vector<hipEvent_t> oth_ev;
+    size_t oth_used = 0;
+    float oth_ms = 0.f;
+    long long oth_launches = 0;
+    double upd_all_bytes = 0.0;             // SURVEY 8d bytes of EVERY panel of the sweep on ALL its trailing columns
 };

@@ -28,7 +28,7 @@ namespace gn {
 constexpr int SB_KMAX = 64;                  // candidate columns per block (LDS permitting)
 constexpr int SB_NMAX = 1024;
 
-#ifdef ENLSIP_SB_STEP_STAMPS     // diagnostic build only (tests/sb_step_probe.py)
+#ifdef ENLSIP_SB_STEP_STAMPS     // diagnostic build only (tests/probes/sb_step_probe.py)
 __device__ long long g_sb_phase[16];
 __device__ long long g_sb_blk[8];      // block-level phases of k_sb_factor_reg, [7] = blocks
 #endif

@@ -17,7 +17,7 @@
 
 namespace gn {
 
-#ifdef ENLSIP_SB_STEP_STAMPS     // diagnostic build only (tests/sb_step_probe.py): phase times of a pivot step, summed over the steps of wave 0 of problem prob0 (g_sb_phase: gn_kernels_qrcp_block.hpp)
+#ifdef ENLSIP_SB_STEP_STAMPS     // diagnostic build only (tests/probes/sb_step_probe.py): phase times of a pivot step, summed over the steps of wave 0 of problem prob0 (g_sb_phase: gn_kernels_qrcp_block.hpp)
 #define SB_PH(i) do { __builtin_amdgcn_sched_barrier(0); if (sb_st) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = wall_clock64(); sb_acc[i] += t_ - sb_t; sb_t = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SB_PH(i) do { } while (0)
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
         SB_PH(4);       // norm downdate
         // position bookkeeping (wave 0): pivot at position q <-> column cj that sat at position j.  Wave 0 has the time: the two
         // waves of a SIMD share its issue slots and the older one (waves 0..3) has priority, so waves 4..7 reach the barrier
-        // ~0.5 us later anyway (phase stamps per wave, tests/sb_step_probe.py); done by the owner's neighbour under the owner's
+        // ~0.5 us later anyway (phase stamps per wave, tests/probes/sb_step_probe.py); done by the owner's neighbour under the owner's
         // reflector construction instead, the step takes the same time.
         if (wl == 0) {
             const int pc = L.ccol[ci];

@@ -414,8 +414,13 @@ __device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, doub
 // the same tile keep it hot in the XCD's L2 (as a launch of its own, after the block kernel, it re-read 400 MB of reflectors per
 // panel from HBM and gave the gain back).  256 threads: thread = row pair of a 512-row tile (RPL = 8); RPL = 4 uses 128 of them.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The 32 x 32 product w2 = -T' w1 used to read T from global memory inside a lane-bounded loop (one exposed load latency per
+// iteration: ~20 us per block reflector, which made this workgroup as expensive as a whole 32-column block of the MFMA body:
+// ~0.3 ms of every far-update launch of a C2 step).  T is now requested first of all (4 doubles per thread, coalesced), parked
+// in LDS with leading dimension 33 (lane k reads T[l + 33 k]: conflict-free) and the product runs fully unrolled on registers.
 template <int RPL, bool PAIR>
-__device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB], double* w2s) {
+__device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB], double* w2s, double* Tl) {
+    constexpr int TLD = PB + 1;
     constexpr int NWV = 4;                                               // waves of the block kernel's workgroup
     const int prob = blockIdx.z + a.prob0;
     const ProbState st = a.state[prob];
@@ -436,13 +441,20 @@ __device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB
     if (PAIR && !has_next) return;                                       // served by the plain kernel (a.pair == 2)
     if (!PAIR && a.pair == 2 && has_next) return;
     constexpr int napp = PAIR ? 2 : 1;
+    // the T blocks of every application: 1024 doubles each = 4 per thread (256 threads), in flight before anything else
+    v4_d2 tl[napp][2];
+#pragma unroll
+    for (int ai = 0; ai < napp; ++ai) {
+        const double* T = a.Tbuf + prob * a.sT + ((ai ? a.tOff2 : a.tOff) + g) * (long long)(PB * PB);
+        tl[ai][0] = *(const v4_d2*)(T + 2 * tid);
+        tl[ai][1] = *(const v4_d2*)(T + 512 + 2 * tid);
+    }
 #pragma unroll
     for (int ai = 0; ai < napp; ++ai) {
         const int r0 = r0a + PB * ai;
         const int bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
         const int col0 = st.rankA + r0;
         const int dsh = 32 * (a.skip + ai);                              // slot of reflector j's diagonal = j + dsh
-        const double* T = a.Tbuf + prob * a.sT + ((ai ? a.tOff2 : a.tOff) + g) * (long long)(PB * PB);
         // V row pairs (structure of the tile's first rows: zero above the diagonal, one on it; columns >= bw do not exist)
         v4_d2 v[PB];
         const double* vrow = Wm + (size_t)col0 * a.ldw + tile_row0 + s0;
@@ -472,17 +484,32 @@ __device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB
                 for (int u = 0; u < 8; ++u) part[w][j8 + u] = rs[u];
             }
         }
-        __syncthreads();
-        // w2 = -T' w1 (T upper triangular, column-major): lane k of wave 0
-        if (w == 0 && ln < PB) {
-            double acc = 0.0;
-            for (int l = 0; l <= ln; ++l) {
-                double w1 = 0.0;
+        // T (column-major, element e = l + 32 k) to LDS as Tl[l + 33 k]; the previous application's readers passed the barrier
+        // that closed it
 #pragma unroll
-                for (int ww = 0; ww < NWV; ++ww) w1 += part[ww][l];
-                acc += T[l + ln * PB] * w1;
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int e = 512 * q + 2 * tid + e2;
+                Tl[(e & 31) + TLD * (e >> 5)] = tl[ai][q][e2];
             }
-            w2s[ln] = (ln < bw) ? -acc : 0.0;
+        __syncthreads();
+        // w2 = -T' w1 (T upper triangular, column-major): lane k of wave 0; w1[l] travels by readlane
+        if (w == 0) {
+            double w1 = 0.0;
+            if (ln < PB) {
+#pragma unroll
+                for (int ww = 0; ww < NWV; ++ww) w1 += part[ww][ln];
+            }
+            double acc = 0.0;
+            const int lk = ln & 31;
+#pragma unroll
+            for (int l = 0; l < PB; ++l) {
+                const double w1l = readlane_f64(w1, l);
+                const double tv = Tl[l + TLD * lk];
+                acc += (l <= lk) ? tv * w1l : 0.0;
+            }
+            if (ln < PB) w2s[ln] = (ln < bw) ? -acc : 0.0;
         }
         __syncthreads();
         if (live) {
@@ -561,7 +588,7 @@ __global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update
 
     V4_STAMP(6);
     if (!TRI && a.skip_rhs && blockIdx.y == gridDim.y - 1) {             // the carried right-hand side of this tile
-        v4_rhs_body<RPL, false>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l);
+        v4_rhs_body<RPL, false>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l, &stage[1][0]);
         return;
     }
     V4Ctx c;
@@ -588,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4_pair(CaqrArgs a) {
 
     V4_STAMP(6);
     if (a.skip_rhs && blockIdx.y == gridDim.y - 1) {
-        v4_rhs_body<RPL, true>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l);
+        v4_rhs_body<RPL, true>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l, &stage[1][0]);
         return;
     }
     V4Ctx c;

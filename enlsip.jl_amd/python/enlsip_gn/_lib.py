@@ -88,6 +88,8 @@ PROTOTYPES = {
     "enlsip_gn_get_stage_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "enlsip_gn_get_update_stats": (C.c_int, [_h, C.POINTER(C.c_float), _ip, _dp]),
     "enlsip_gn_get_update_table": (C.c_int, [_h, C.c_int64, _dp, C.POINTER(C.c_float), _ip]),
+    "enlsip_gn_get_launch_plan": (C.c_int, [_h, _ip, C.POINTER(C.c_int), _ip]),
+    "enlsip_gn_get_update_totals": (C.c_int, [_h, C.POINTER(C.c_float), C.POINTER(C.c_float), _ip, _dp]),
     "enlsip_gn_measure_stream": (C.c_int, [_h, C.c_int64, C.c_int, _dp]),
     "enlsip_gn_debug_copy_W": (C.c_int, [_h, C.c_int64, _dp, _ip, C.c_int64]),
 }

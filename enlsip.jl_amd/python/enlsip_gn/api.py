@@ -285,6 +285,25 @@ class GNSolver:
         self._chk(self._lib.enlsip_gn_get_update_table(self._h, cap, by, ms, C.byref(cnt)))
         return [(float(by[i]), float(ms[i])) for i in range(min(int(cnt.value), cap))]
 
+    def launch_plan(self):
+        """(pipeline_split, panel_pairs, tile_rows) of the last solve: what the library chose on its own."""
+        sp, pr, tr = C.c_int64(), C.c_int(), C.c_int64()
+        self._chk(self._lib.enlsip_gn_get_launch_plan(self._h, C.byref(sp), C.byref(pr), C.byref(tr)))
+        return int(sp.value), bool(pr.value), int(tr.value)
+
+    def pipeline_split(self) -> int:
+        return self.launch_plan()[0]
+
+    def plan_uses_pairs(self) -> bool:
+        return self.launch_plan()[1]
+
+    def update_totals(self):
+        """(far_ms, other_ms, other_launches, all_panels_bytes) of the last profiled solve: HIP-event time of the level-0 far
+        passes and of every other trailing-update launch (tree levels, second-panel columns); SURVEY 8d bytes of all panels."""
+        far, oth, cnt, by = C.c_float(), C.c_float(), C.c_int64(), C.c_double()
+        self._chk(self._lib.enlsip_gn_get_update_totals(self._h, C.byref(far), C.byref(oth), C.byref(cnt), C.byref(by)))
+        return float(far.value), float(oth.value), int(cnt.value), float(by.value)
+
     def measure_stream(self, nbytes: int = 1 << 30, reps: int = 5) -> float:
         """GB/s of an in-place non-temporal read-modify-write stream with the trailing update's access shape on this device."""
         out = C.c_double(0.0)

@@ -287,8 +287,9 @@ int enlsip_gn_tsqr_get_transport(enlsip_gn_handle h, int* transport);
 enum {
     ENLSIP_GN_STAGE_CONSTRAINT = 0, /* F_A, F_L11, p1, T factor            */
     ENLSIP_GN_STAGE_JQ1 = 1,        /* J*Q1 and d_temp                      */
-    ENLSIP_GN_STAGE_PANEL = 2,      /* all CAQR panel factorisations        */
-    ENLSIP_GN_STAGE_UPDATE = 3,     /* all trailing updates                 */
+    ENLSIP_GN_STAGE_PANEL = 2,      /* all CAQR panel factorisations (tiles and tree nodes)                     */
+    ENLSIP_GN_STAGE_UPDATE = 3,     /* EVERY trailing-update launch of the sweep: the level-0 far passes, the tree
+                                     * levels and a pair's second-panel columns (sum of their HIP-event times)  */
     ENLSIP_GN_STAGE_PIVOT = 4,      /* pivoted QR of R0 + triangular solves */
     ENLSIP_GN_STAGE_TOTAL = 5,
     ENLSIP_GN_STAGE_COUNT = 6
@@ -304,10 +305,21 @@ int enlsip_gn_get_update_stats(enlsip_gn_handle h, float* avg_ms, int64_t* launc
  * bytes 8 (2 m_k n_k + m_k b + b^2) of the panels the launch applies, and its HIP-event time.  *count = launches recorded;
  * at most cap entries are written. */
 int enlsip_gn_get_update_table(enlsip_gn_handle h, int64_t cap, double* algorithmic_bytes, float* ms, int64_t* count);
+/* How the last solve on this handle was launched (what the library chose on its own): *pipeline_split = number of problems the
+ * first of the two pipelined halves owned (0: one stream), *panel_pairs = 1 when the CAQR sweep applied two panels per pass over
+ * the far trailing columns, *tile_rows = rows of a level-0 CAQR tile.  Tests use it to assert that a configuration really took
+ * the path a benchmark times. */
+int enlsip_gn_get_launch_plan(enlsip_gn_handle h, int64_t* pipeline_split, int* panel_pairs, int64_t* tile_rows);
+/* All trailing-update launches of the last profiled solve: HIP-event time of the level-0 far passes (the launches of
+ * enlsip_gn_get_update_table) and of every OTHER update launch (tree levels, second-panel columns), and SURVEY 8d's
+ * 8 (2 m_k n_k + m_k b + b^2) summed over EVERY panel of the sweep with n_k = all columns right of the panel (times the batch):
+ * bytes / (far_ms + other_ms) is the trailing update's rate counted over all of its kernels (bench.py: roofline.all_update_kernels) */
+int enlsip_gn_get_update_totals(enlsip_gn_handle h, float* far_ms, float* other_ms, int64_t* other_launches,
+                                double* all_panels_bytes);
 /* GB/s (read + write) of an in-place non-temporal read-modify-write stream over `bytes` of the handle's scratch memory with the
  * trailing update's access shape, HIP events around `reps` passes: the same-box ceiling of an in-place update (bench.py) */
 int enlsip_gn_measure_stream(enlsip_gn_handle h, int64_t bytes, int reps, double* gbytes_per_s);
-/* Debugging aid (tests/pair_probe_w*.py): copies the working matrix W of problem `prob` (ldw x (n + 1): J*Q1 with the CAQR factors of
+/* Debugging aid (tests/probes/pair_probe_w*.py): copies the working matrix W of problem `prob` (ldw x (n + 1): J*Q1 with the CAQR factors of
  * [J2 | d] in place) as it stands to host memory; *ldw_out = its leading dimension; -3 when cap_doubles is too small.  Together with
  * ENLSIP_GN_DEBUG_MAXPAN / ENLSIP_GN_DEBUG_STAGE (stop the CAQR sweep after so many panels / inside the first pair) this is how an
  * orthogonality defect is located stage by stage. */

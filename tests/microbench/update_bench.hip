@@ -28,8 +28,11 @@ int main(int argc, char** argv) {
     const int batch = argc > 1 ? atoi(argv[1]) : 256;
     const int panel = argc > 2 ? atoi(argv[2]) : 0;
     const int level = argc > 3 ? atoi(argv[3]) : 0;
-    const int m = 4096, n = 512, t = 64, RPL = 8, F = 16;
-    const int ldw = 4128;
+    // UB_M: row count (default 4096; ldw follows make_plan's rule); UB_PAIR_ONLY=1: time only the pair's far update
+    const int m = getenv("UB_M") ? atoi(getenv("UB_M")) : 4096;
+    const bool pair_only = getenv("UB_PAIR_ONLY") != nullptr;
+    const int n = 512, t = 64, RPL = 8, F = 16;
+    const int ldw = (m % 512 == 0) ? m + 32 : m;
     const long long sW = (long long)ldw * (n + 1 + 32);   // 32 spare columns (make_plan does the same)
     const int n2 = n - t, kp = n2;
     int nblocks = m / 32 - panel;           // level 0
@@ -65,7 +68,7 @@ int main(int argc, char** argv) {
     a.mode = level == 0 ? 0 : 1; a.base = 32 * panel; a.skip = 0; a.win = 0; a.pair = 0; a.tOff2 = 0;
 
     // ---- host check of problem 0: C - V (T' (V' C)) in plain loops on sampled columns ---------------------
-    {
+    if (!pair_only) {
         launch_update_v4(RPL, a, groups, ntrail, 1, 0);
         CK(hipDeviceSynchronize());
         std::vector<double> r1((size_t)sW);
@@ -162,6 +165,15 @@ int main(int argc, char** argv) {
         const double rk = (double)nblocks * 32;
         const double b1 = (double)batch * 8.0 * (2.0 * rk * ntrail + rk * 32), b2 = (double)batch * 8.0 * (2.0 * (rk - 32) * nfar + (rk - 32) * 32);
         const double bn = (double)batch * 8.0 * (2.0 * rk * 32 + rk * 32), bf = (double)batch * 8.0 * (2.0 * rk * nfar + rk * 32) + b2;
+        if (pair_only) {
+            // UB_EXACT=1: the grid covers the far columns only (no column block that exits at once: the library's grid spans ntrail)
+            const int gcols = getenv("UB_EXACT") ? nfar - ap.skip_rhs : ntrail - ap.skip_rhs;
+            const float t4 = timeit("pair, far columns", [&] { launch_update_v4(RPL, ap, groups, gcols, batch, 0); }, bf);
+            const int ncb = (nfar - 1) / 32;
+            printf("PAIRONLY m %d panel %d blocks %d nfar %d : %.3f ms  per column block %.4f ms  per (block x unit) %.3f ns\n", m, panel, nblocks, nfar, t4, t4 / ncb,
+                   t4 / ncb / nblocks * 1e6);
+            return 0;
+        }
         for (int rep = 0; rep < 2; ++rep) {
             const float t1 = timeit("plain pass, first panel", [&] { launch_update_v4(RPL, a1, groups, ntrail - a1.skip_rhs, batch, 0); }, b1);
             const float t2 = timeit("plain pass, second panel", [&] { launch_update_v4(RPL, a2, g2, nfar - a2.skip_rhs, batch, 0); }, b2);

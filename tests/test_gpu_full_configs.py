@@ -121,6 +121,25 @@ def test_c3_full_batch(solver):
     _check_sample_against_oracle(J, rx, At, cx, p, d, info, jJ, _sample(B))
 
 
+def test_c2_bench_path_batch_256(solver):
+    """The path `bench.py` itself times (BASELINE configs[1] as a resident batch): 256 x (m=4096, n=512, t=64) in ONE call on the
+    device, with the library's own choices — automatic panel pairs (far update of the first pair >= 8192 workgroups) AND the two
+    pipelined halves (batch >= 128: second half on the child handle's stream, driven by a host thread).  Every problem by its
+    optimality conditions; the first and last problem of EACH half and a random sample against the LAPACK oracle on the same
+    numbers (p, ranks, code, jpvtJ2, |d|: src/enlsip_functions.jl:206-234 at the bench's own batch)."""
+    from enlsip_gn import workload as wl
+    B, m, n, t = 256, 4096, 512, 64
+    J, rx, At, cx = wl.make_batch(0, B, m, n, t, "cuda:0")
+    p, b, d, info, jJ = _solve_batch_dev(solver, J, rx, At, cx)
+    assert solver.pipeline_split() == B // 2, "the batch was not split over the two pipelined halves"
+    assert solver.plan_uses_pairs(), "the sweep did not pair its panels"
+    _check_all_problems(J, rx, At, cx, p, d, info, chunk=32)
+    half = B // 2
+    rng = np.random.default_rng(4096)
+    sample = sorted({0, half - 1, half, B - 1, *[int(k) for k in rng.integers(0, B, size=4)]})
+    _check_sample_against_oracle(J, rx, At, cx, p, d, info, jJ, sample)
+
+
 def test_c3_unconstrained_variant(solver):
     """SURVEY 8d lists a t = 0 variant of C3."""
     from enlsip_gn import workload as wl

@@ -1,6 +1,6 @@
 """Robustness of the HIP path (GPU): one handle reused across random shapes with degenerate / non-finite inputs (two GPU memory
 faults were found this way, profiles/r1_notes.md), and padded leading dimensions / strides on the device entry.  Longer versions:
-tests/stress_reuse.py, tests/ld_padding.py, tests/stress_pipelined.py, tests/stress_tsqr.py."""
+tests/probes/stress_reuse.py, tests/probes/ld_padding.py, tests/probes/stress_pipelined.py, tests/probes/stress_tsqr.py."""
 import os
 
 import numpy as np
@@ -332,6 +332,15 @@ def test_update_table_and_stream_ceiling():
             table = s.update_table()
             assert cnt == len(table) == launches and avg_ms > 0
             assert abs(sum(b for b, _ in table) - total) <= 1e-9 * total and all(ms > 0 for _, ms in table)
+            # all trailing-update launches: the far passes above + tree levels / second-panel columns; SURVEY 8d bytes of ALL
+            # seven panels on every column right of them (the same number whichever way the sweep is launched)
+            far_ms, other_ms, other_cnt, all_bytes = s.update_totals()
+            mpad = 2048
+            want = batch * sum(8.0 * (2.0 * (mpad - 32 * k) * (224 + 1 - 32 * (k + 1)) + (mpad - 32 * k) * 32 + 1024) for k in range(7))
+            assert abs(all_bytes - want) <= 1e-9 * want
+            assert abs(far_ms - avg_ms * cnt) <= 1e-3 * far_ms and other_ms > 0 and other_cnt > 0
+            st = s.stage_ms()
+            assert abs(st["update"] - (far_ms + other_ms)) <= 1e-3 * st["update"] and st["panel"] > 0
             if pair:
                 gbs = s.measure_stream(1 << 28, 3)
                 assert 1000.0 < gbs < 8000.0            # an MI355X streams 5-6 TB/s in place; anything else is a broken measurement

@@ -20,6 +20,21 @@ def _status_key(exit_code):
 PROBLEMS = {"chained_rosenbrock_1000": lambda: rp.chained_rosenbrock(1000), "chained_wood_20": lambda: rp.chained_wood(20),
             "osborne2": rp.osborne2}
 _ref_cache = {}
+_env_cache = {}
+# problems whose oracle run takes seconds: their step-length tolerance is MEASURED (tests/perturbation_envelope.py); the
+# 1000-variable chained Rosenbrock run takes most of a minute per repetition and keeps the fixed bound
+ENVELOPE_PROBLEMS = ("chained_wood_20", "osborne2")
+ALPHA_FLOOR = 1e-7          # relative step-length agreement asked for where rounding-level perturbations do not move it at all
+ENVELOPE_FACTOR = 10.0      # x the spread seen under +-1 ulp perturbations of the subproblem's inputs (six draws)
+
+
+def _alpha_envelope(name):
+    """Per-iteration spread of the step length under rounding-level perturbations of the oracle's own inputs."""
+    import perturbation_envelope as pe
+    if name not in _env_cache:
+        ref = _oracle_run(name)
+        _env_cache[name] = pe.alpha_envelope(lambda backend: rp.run(PROBLEMS[name](), backend), ref)
+    return _env_cache[name]
 
 
 def _oracle_run(name):
@@ -41,6 +56,20 @@ def test_reference_problem_oracle_backend(name):
         assert np.all(res.x >= np.array(P["x_low"]) - 1e-10) and np.all(res.x <= np.array(P["x_upp"]) + 1e-10)
 
 
+@pytest.mark.parametrize("name", ENVELOPE_PROBLEMS)
+def test_step_length_envelope_under_ulp_perturbations(name):
+    """The yardstick of the iteration-for-iteration comparison: perturbing J and r of every subproblem by one unit in the last
+    place leaves every discrete outcome of the run alone (codes, ranks, working-set sizes, iteration count) and moves the early
+    step lengths by rounding noise only — but the line search of Osborne 2's end game amplifies it to 1e-5 .. 1e-2 (which is why a
+    fixed 1e-6 bound once vetoed a legitimate change of summation order)."""
+    ref = _oracle_run(name)
+    env, agree_upto = _alpha_envelope(name)
+    assert agree_upto >= len(ref.trace), "a 1-ulp perturbation changed a discrete decision of the run"
+    assert env[: min(6, len(env))].max() <= 1e-12
+    if name == "osborne2":
+        assert env.max() > 1e-6          # the knife edge is real: the old fixed bound sat below the 1-ulp envelope
+
+
 def test_time_limit_status():
     from oracle import enlsip_outer as eo
     res = rp.run(rp.chained_rosenbrock(200), eo.OracleBackend(), time_limit=-1.0)
@@ -56,14 +85,22 @@ def test_reference_problem_hip_backend_iteration_for_iteration(name):
     s = GNSolver(device=0)
     res = rp.run(PROBLEMS[name](), HipBackend(s))
     s.close()
+    # discrete outcomes: exact
     assert res.exit_code == ref.exit_code and res.iterations == ref.iterations
+    env = _alpha_envelope(name)[0] if name in ENVELOPE_PROBLEMS else None
     f_prev = None
-    for a, b in zip(res.trace, ref.trace):
+    for i, (a, b) in enumerate(zip(res.trace, ref.trace)):
         assert (a["code"], a["t"], a["rankA"], a["rankJ2"]) == (b["code"], b["t"], b["rankA"], b["rankJ2"])
         assert abs(a["f"] - b["f"]) <= 1e-8 * max(1.0, abs(b["f"]))
-        # the step length of the line search is only determined while the objective still moves: in the flat end game of
-        # Osborne 2 (|f_k - f_{k-1}| < 1e-8 f) it drifts by up to 1e-3 between two runs whose objectives agree to 1e-16
-        flat = f_prev is not None and abs(b["f"] - f_prev) <= 1e-8 * max(1.0, abs(b["f"]))
-        assert abs(a["alpha"] - b["alpha"]) <= (5e-3 if flat else 1e-6) * max(1.0, abs(b["alpha"]))
+        # step length: within ENVELOPE_FACTOR x what +-1 ulp on the subproblem's inputs does to the ORACLE's own step length at
+        # this iteration (measured, tests/perturbation_envelope.py), and within ALPHA_FLOOR where that is nothing.  Osborne 2's
+        # end game: 1e-5 .. 1e-2 from iteration 12 on.  Without a measured envelope (chained Rosenbrock): 1e-6, and 5e-3 once the
+        # objective has stopped moving (|f_k - f_{k-1}| < 1e-8 f), where the step length is no longer determined.
+        if env is not None:
+            tol = max(ALPHA_FLOOR, ENVELOPE_FACTOR * env[i])
+        else:
+            flat = f_prev is not None and abs(b["f"] - f_prev) <= 1e-8 * max(1.0, abs(b["f"]))
+            tol = 5e-3 if flat else 1e-6
+        assert abs(a["alpha"] - b["alpha"]) <= tol * max(1.0, abs(b["alpha"])), (i, a["alpha"], b["alpha"], tol)
         f_prev = b["f"]
     assert np.abs(res.x - ref.x).max() <= 1e-7 * max(1.0, np.abs(ref.x).max())
