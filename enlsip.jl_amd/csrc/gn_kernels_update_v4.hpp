@@ -59,6 +59,22 @@ __device__ long long g_v4_stamps[8 * 8];
 #ifndef ENLSIP_V4_PREFETCH_NEXT
 #define ENLSIP_V4_PREFETCH_NEXT 1
 #endif
+// Pair kernel, last pass: the stores of unit g are issued at the START of unit g + 1, right behind the request for that unit's
+// second piece of V, instead of at the end of unit g.  vmcnt counts loads and stores in ONE in-order queue on this target: a
+// wait for a load that was issued after a store also waits for that store's write acknowledgement from HBM.  With the stores
+// at the end of a unit the very next piece of V (requested behind them) paid that acknowledgement half a unit later.
+#ifndef ENLSIP_V4_LATE_STORE
+#define ENLSIP_V4_LATE_STORE 1
+#endif
+#ifndef ENLSIP_V4_NT_STORE
+#define ENLSIP_V4_NT_STORE 1
+#endif
+#ifndef ENLSIP_V4_IMM_UNIT
+#define ENLSIP_V4_IMM_UNIT 1
+#endif
+#ifndef ENLSIP_V4_START_FENCE
+#define ENLSIP_V4_START_FENCE 1
+#endif
 constexpr int V4_LD = 34;                    // leading dimension of the per-wave transpose images
 constexpr int V4_IMG = PB * V4_LD;           // doubles per image (C or V), 32 columns
 constexpr int V4_STAGE = 2 * V4_IMG;         // per wave: C image + V image (also hosts the wave's W1 partial)
@@ -123,12 +139,24 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     auto ap_bw = [&](int ai) -> int { return ai ? c.bw2 : c.bw; };
     auto ap_dshift = [&](int ai) -> int { return ai ? c.dshift2 : c.dshift; };
     const bool dense_unit = TRI && c.mode == 2 && (w & 1);   // mode 2: odd blocks are dense (gblk0 is even)
+    // Level 0: unit g of this wave starts 128 g doubles behind its unit 0, so ONE uniform base per column (independent of g)
+    // serves every unit and 1024 g bytes ride in the immediate offset of the access: 8 + 8 per block reflector scalar bases
+    // instead of one per (unit, column) — those did not fit the scalar file (1200 scalar spills into vector lanes, the reloads
+    // in the middle of the MFMA chains).
     auto cptr = [&](int g, int ct, int r) -> double* {
         if (GATHER) return (double*)((char*)(c.C + rowu(g)) + (coff[4 * ct + r] + 16u * (unsigned)lr));
+        if (!TRI && ENLSIP_V4_IMM_UNIT) {
+            double* ub = c.C + (size_t)(c.cb0 + 16 * ct + 4 * r) * c.ldw + (c.tile_row0 + 32 * w);      // uniform
+            return (double*)((char*)ub + lane_byte) + 128 * g;
+        }
         double* ub = c.C + (size_t)(c.cb0 + 16 * ct + 4 * r) * c.ldw + rowu(g);      // uniform
         return (double*)((char*)ub + lane_byte);
     };
     auto vptr = [&](int ai, int g, int ks) -> const double* {
+        if (!TRI && ENLSIP_V4_IMM_UNIT) {
+            const double* ub = c.Wm + (size_t)(ap_col0(ai) + 4 * ks) * c.ldw + (c.tile_row0 + 32 * w);      // uniform
+            return (const double*)((const char*)ub + lane_byte) + 128 * g;
+        }
         const double* ub = c.Wm + (size_t)(ap_col0(ai) + 4 * ks) * c.ldw + rowu(g);       // uniform
         return (const double*)((const char*)ub + lane_byte);
     };
@@ -166,12 +194,14 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             else vh[k4] = *(const v4_d2*)vptr(ai, g, 4 * h + k4);
         }
     };
-    auto finish_v = [&](int ai, int g, int h, v4_d2 (&vh)[4]) {   // structure of V: unit trapezoid / identity + triangles
-        const int s0 = slot0(g) + 2 * lr;
+    // lrx / lqx: the calling phase's own (opaque) copy of the lane coordinates, so that the masks are recomputed per phase
+    // instead of being kept — i.e. spilled — from product 1 to product 2
+    auto finish_v = [&](int ai, int g, int h, v4_d2 (&vh)[4], const int lrx, const int lqx) {   // structure of V: unit trapezoid / identity + triangles
+        const int s0 = slot0(g) + 2 * lrx;
         const int dsh = ap_dshift(ai);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
-            const int j = 16 * h + 4 * k4 + lq;
+            const int j = 16 * h + 4 * k4 + lqx;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int s = s0 + p;
@@ -198,6 +228,13 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
 #pragma unroll
     for (int ai = 0; ai < NAP; ++ai) {
         const bool first_app = (ai == 0), last_app = (ai == NAP - 1);
+        // LDS addresses are formed from per-phase opaque copies of the lane index: the compiler otherwise computes the
+        // address registers of EVERY phase of BOTH passes at kernel entry (common subexpressions) and spills them across the
+        // phases in between — and a scratch reload is a vector-memory operation: its wait is vmcnt(0), which also drains
+        // every prefetch in flight (19 such drains per workgroup in the hot variant).
+        int lnp = ln;
+        asm volatile("" : "+v"(lnp));
+        const int lrp = lnp & 15, lqp = lnp >> 4;
         // ---- product 1: per-wave partial W1 = V' C ------------------------------------------------------------
         if (first_app) V4_STAMP(0);
         v4_d4 acc[2][2];
@@ -223,31 +260,34 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             if (first_app) {
                 issue_c(0);
                 if (NGW > 1) issue_c(1);
+                // every request of the first two units is on its way before the first select on a loaded value (the scheduler
+                // used to hoist V's structure selects above the C loads: two memory latencies in a row at kernel start)
+                if (ENLSIP_V4_START_FENCE) __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int g = 0; g < NGW; ++g) {
                 // transpose images of unit g (the previous unit's reads were issued before: LDS keeps a wave's order)
-                finish_v(ai, g, 0, vp[0]);
-                finish_v(ai, g, 1, vp[1]);
+                finish_v(ai, g, 0, vp[0], lrp, lqp);
+                finish_v(ai, g, 1, vp[1], lrp, lqp);
                 if (first_app) {
                     finish_c(g);
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) *(v4_d2*)&Vs[(4 * ks + lq) * V4_LD + 2 * lr] = vp[ks >> 2][ks & 3];
+                    for (int ks = 0; ks < 8; ++ks) *(v4_d2*)&Vs[(4 * ks + lqp) * V4_LD + 2 * lrp] = vp[ks >> 2][ks & 3];
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) *(v4_d2*)&Cs[(16 * ct + lq + 4 * r) * V4_LD + 2 * lr] = cp[g][ct][r];
+                        for (int r = 0; r < 4; ++r) *(v4_d2*)&Cs[(16 * ct + lqp + 4 * r) * V4_LD + 2 * lrp] = cp[g][ct][r];
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-                        for (int p = 0; p < 2; ++p) Vs[(4 * ks + lq) * V4_LD + 16 * p + lr] = vp[ks >> 2][ks & 3][p];
+                        for (int p = 0; p < 2; ++p) Vs[(4 * ks + lqp) * V4_LD + 16 * p + lrp] = vp[ks >> 2][ks & 3][p];
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
-                            for (int p = 0; p < 2; ++p) Cs[(16 * ct + lq + 4 * r) * V4_LD + 16 * p + lr] = cf[g][p][ct][r];
+                            for (int p = 0; p < 2; ++p) Cs[(16 * ct + lqp + 4 * r) * V4_LD + 16 * p + lrp] = cf[g][p][ct][r];
                 }
                 // next operands: V one unit ahead (same registers), C two units ahead (its own registers)
                 if (g + 1 < NGW) {
@@ -265,11 +305,11 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                     double av[2][4], bv[2][4];
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
-                        const int kr = 16 * kh + 4 * k4 + lq;            // row of the unit = contraction index
+                        const int kr = 16 * kh + 4 * k4 + lqp;           // row of the unit = contraction index
 #pragma unroll
-                        for (int it = 0; it < 2; ++it) av[it][k4] = Vs[(16 * it + lr) * V4_LD + kr];
+                        for (int it = 0; it < 2; ++it) av[it][k4] = Vs[(16 * it + lrp) * V4_LD + kr];
 #pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) bv[ct][k4] = Cs[(16 * ct + lr) * V4_LD + kr];
+                        for (int ct = 0; ct < NCT; ++ct) bv[ct][k4] = Cs[(16 * ct + lrp) * V4_LD + kr];
                     }
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
@@ -290,12 +330,15 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         if (NGW > 0) issue_v(ai, 0, 0, vb[0]);               // travels during the reduction step
 
         // ---- reduction over waves fused with W2 = -T' W1 (the partial goes to the wave's own stage) ----------
+        int lnr = ln;
+        asm volatile("" : "+v"(lnr));
+        const int lrr = lnr & 15, lqr = lnr >> 4;
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stage[w][(16 * it + lq + 4 * r) * PB + 16 * ct + lr] = acc[it][ct][r];
+                for (int r = 0; r < 4; ++r) stage[w][(16 * it + lqr + 4 * r) * PB + 16 * ct + lrr] = acc[it][ct][r];
         if (first_app && NAP == 1) V4_STAMP(2);
         __syncthreads();
         if (first_app && NAP == 1) V4_STAMP(3);
@@ -303,14 +346,14 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             v4_d4 t = (v4_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const int l = 4 * ks + lq, k = 16 * it2 + lr;
-                const int o = l * PB + 16 * ct2 + lr;
+                const int l = 4 * ks + lqr, k = 16 * it2 + lrr;
+                const int o = l * PB + 16 * ct2 + lrr;
                 const double b = (stage[0][o] + stage[1][o]) + (stage[2][o] + stage[3][o]);
                 const double ta = (l <= k && k < ap_bw(ai)) ? tA[ks] : 0.0;
                 t = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, b, t, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W2l[(16 * it2 + lq + 4 * r) * PB + ((16 * ct2 + lr) ^ (16 * (lq & 1)))] = -t[r];   // swizzled, see the read
+            for (int r = 0; r < 4; ++r) W2l[(16 * it2 + lqr + 4 * r) * PB + ((16 * ct2 + lrr) ^ (16 * (lqr & 1)))] = -t[r];   // swizzled, see the read
         }
         __syncthreads();
         if (first_app) V4_STAMP(4);
@@ -318,6 +361,29 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
 
         // ---- product 2: D^T[col][row pair] += W2^T V^T, even and odd rows of each unit; stored by the last pass,
         //      back into the registers otherwise ---------------------------------------------------------------------
+        int lnq = ln;
+        asm volatile("" : "+v"(lnq));
+        const int lrq = lnq & 15, lqq = lnq >> 4;
+        constexpr bool LATE = (NAP > 1) && ENLSIP_V4_LATE_STORE && !RMASK;
+        auto store_unit = [&](int g, const v4_d4 (&fr)[2][2]) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (V4_ABLATE == 3 || V4_ABLATE == 5) {
+                        if (fr[0][ct][r] == 1.2345e301) c.C[0] = fr[1][ct][r];
+                    } else if (CFULL || ((smask >> (4 * ct + r)) & 1u)) {
+                        if (!RMASK) {
+                            if (ENLSIP_V4_NT_STORE) __builtin_nontemporal_store((v4_d2){fr[0][ct][r], fr[1][ct][r]}, (v4_d2*)cptr(g, ct, r));
+                            else *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
+                        } else {
+                            const int s0 = slot0(g) + 2 * lr;
+                            if (s0 + 1 < c.rows_valid) *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
+                            else if (s0 < c.rows_valid) *cptr(g, ct, r) = fr[0][ct][r];
+                        }
+                    }
+                }
+        };
 #pragma unroll
         for (int g = 0; g < NGW; ++g) {
             v4_d4 fr[2][2];                                  // [p][ct]
@@ -340,15 +406,19 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             for (int h = 0; h < 2; ++h) {
                 const int u = 2 * g + h;                     // piece index; piece u + 1 is fetched while u is used
                 if (u + 1 < 2 * NGW) issue_v(ai, (u + 1) >> 1, (u + 1) & 1, vb[(u + 1) & 1]);
+                if (LATE && last_app && h == 0 && g > 0) {    // the previous unit's results, parked in cf: both pieces of THIS unit are in flight
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_unit(g - 1, cf[g - 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                finish_v(ai, g, h, vb[u & 1]);
+                finish_v(ai, g, h, vb[u & 1], lrq, lqq);
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     double a2[4];
 #pragma unroll
                     // A[i = col][k]; rows k and k + 1 (the two 16-lane groups of a half-wave) are 256 B apart = same banks, so odd
                     // rows are stored with their two column halves exchanged: conflict-free ds_read_b64
-                    for (int k4 = 0; k4 < 4; ++k4) a2[k4] = W2l[(16 * h + 4 * k4 + lq) * PB + ((16 * ct + lr) ^ (16 * (lq & 1)))];
+                    for (int k4 = 0; k4 < 4; ++k4) a2[k4] = W2l[(16 * h + 4 * k4 + lqq) * PB + ((16 * ct + lrq) ^ (16 * (lqq & 1)))];
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -368,22 +438,12 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                 continue;
             }
             post(g, fr);
+            if (LATE && g + 1 < NGW) {                       // stored at the start of the next unit (see ENLSIP_V4_LATE_STORE)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
+                for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (V4_ABLATE == 3 || V4_ABLATE == 5) {
-                        if (fr[0][ct][r] == 1.2345e301) c.C[0] = fr[1][ct][r];
-                    } else if (CFULL || ((smask >> (4 * ct + r)) & 1u)) {
-                        if (!RMASK) {
-                            __builtin_nontemporal_store((v4_d2){fr[0][ct][r], fr[1][ct][r]}, (v4_d2*)cptr(g, ct, r));
-                        } else {
-                            const int s0 = slot0(g) + 2 * lr;
-                            if (s0 + 1 < c.rows_valid) *(v4_d2*)cptr(g, ct, r) = (v4_d2){fr[0][ct][r], fr[1][ct][r]};
-                            else if (s0 < c.rows_valid) *cptr(g, ct, r) = fr[0][ct][r];
-                        }
-                    }
-                }
+                    for (int ct = 0; ct < 2; ++ct) cf[g][p][ct] = fr[p][ct];
+            } else store_unit(g, fr);
             __builtin_amdgcn_sched_barrier(0);
         }
     }

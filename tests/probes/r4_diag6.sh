@@ -1,0 +1,6 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4f; mkdir -p $O
+tests/microbench/update_bench 64 0 0 | grep -i "check"
+for a in "" _ls0 _nt0 _nt0ls0; do for p in 0 6 10; do UB_EXACT=1 UB_PAIR_ONLY=1 tests/microbench/update_bench$a 384 $p 0 | grep PAIRONLY | sed "s/PAIRONLY/var[$a]/"; done; done > $O/var.txt
+cat $O/var.txt
