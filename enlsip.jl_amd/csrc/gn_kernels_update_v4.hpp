@@ -47,7 +47,7 @@ typedef double v4_d2 __attribute__((ext_vector_type(2)));
 #ifndef ENLSIP_V4_ABLATE
 #define ENLSIP_V4_ABLATE 0
 #endif
-// timing experiments only (results wrong when != 0): 2 no V loads, 3 no C traffic, 4 no MFMA, 5 MFMA only
+// timing experiments only (results wrong when != 0): 2 no V loads, 3 no C traffic, 4 no MFMA, 5 MFMA only, 6 no C stores, 7 no C loads
 constexpr int V4_ABLATE = ENLSIP_V4_ABLATE;
 #ifdef ENLSIP_V4_STAMPS         // harness only (tests/microbench/update_bench.hip): phase stamps (100 MHz) of sample workgroups
 __device__ long long g_v4_stamps[8 * 8];
@@ -64,10 +64,18 @@ __device__ long long g_v4_stamps[8 * 8];
 // wait for a load that was issued after a store also waits for that store's write acknowledgement from HBM.  With the stores
 // at the end of a unit the very next piece of V (requested behind them) paid that acknowledgement half a unit later.
 #ifndef ENLSIP_V4_LATE_STORE
-#define ENLSIP_V4_LATE_STORE 1
+#define ENLSIP_V4_LATE_STORE 0
 #endif
 #ifndef ENLSIP_V4_NT_STORE
 #define ENLSIP_V4_NT_STORE 1
+#endif
+// depth of the V ring of product 2 in pieces of half a unit: 2 = piece u + 1 is requested when piece u is consumed (half a
+// unit = 16 MFMAs ahead), 3 = piece u + 2 (a whole unit ahead; 16 more registers)
+#ifndef ENLSIP_V4_VB_DEPTH
+#define ENLSIP_V4_VB_DEPTH 2
+#endif
+#ifndef ENLSIP_V4_C_AHEAD
+#define ENLSIP_V4_C_AHEAD 2
 #endif
 #ifndef ENLSIP_V4_IMM_UNIT
 #define ENLSIP_V4_IMM_UNIT 1
@@ -170,7 +178,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (V4_ABLATE == 3 || V4_ABLATE == 5) cp[g][ct][r] = (v4_d2){(double)(g + r), (double)ct};
+                if (V4_ABLATE == 3 || V4_ABLATE == 5 || V4_ABLATE == 7) cp[g][ct][r] = (v4_d2){(double)(g + r), (double)ct};
                 else cp[g][ct][r] = __builtin_nontemporal_load((const v4_d2*)cptr(g, ct, r));   // streamed once: keep it out of L2's way
             }
     };
@@ -260,6 +268,10 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             if (first_app) {
                 issue_c(0);
                 if (NGW > 1) issue_c(1);
+                if (ENLSIP_V4_C_AHEAD > 2) {                 // every unit's block of C is requested at once (its registers exist anyway)
+#pragma unroll
+                    for (int g2 = 2; g2 < NGW; ++g2) issue_c(g2);
+                }
                 // every request of the first two units is on its way before the first select on a loaded value (the scheduler
                 // used to hoist V's structure selects above the C loads: two memory latencies in a row at kernel start)
                 if (ENLSIP_V4_START_FENCE) __builtin_amdgcn_sched_barrier(0);
@@ -294,7 +306,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                     issue_v(ai, g + 1, 0, vp[0]);
                     issue_v(ai, g + 1, 1, vp[1]);
                 }
-                if (first_app && g + 2 < NGW) issue_c(g + 2);
+                if (first_app && ENLSIP_V4_C_AHEAD <= 2 && g + 2 < NGW) issue_c(g + 2);
                 if (g == NGW - 1) {
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) tA[ks] = ap_T(ai)[4 * ks + lq + (16 * it2 + lr) * PB];
@@ -326,8 +338,10 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         }
         if (first_app) V4_STAMP(1);
         if (!first_app) V4_STAMP(3);          // pair: product 1 of the second pass done
-        v4_d2 vb[2][4];                                      // ring over (unit, half)
+        constexpr int VBD = ENLSIP_V4_VB_DEPTH;
+        v4_d2 vb[VBD][4];                                    // ring over (unit, half)
         if (NGW > 0) issue_v(ai, 0, 0, vb[0]);               // travels during the reduction step
+        if (NGW > 0 && VBD > 2) issue_v(ai, 0, 1, vb[1]);
 
         // ---- reduction over waves fused with W2 = -T' W1 (the partial goes to the wave's own stage) ----------
         int lnr = ln;
@@ -370,7 +384,7 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (V4_ABLATE == 3 || V4_ABLATE == 5) {
+                    if (V4_ABLATE == 3 || V4_ABLATE == 5 || V4_ABLATE == 6) {
                         if (fr[0][ct][r] == 1.2345e301) c.C[0] = fr[1][ct][r];
                     } else if (CFULL || ((smask >> (4 * ct + r)) & 1u)) {
                         if (!RMASK) {
@@ -405,13 +419,14 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int u = 2 * g + h;                     // piece index; piece u + 1 is fetched while u is used
-                if (u + 1 < 2 * NGW) issue_v(ai, (u + 1) >> 1, (u + 1) & 1, vb[(u + 1) & 1]);
+                constexpr int AH = VBD - 1;                  // pieces ahead
+                if (u + AH < 2 * NGW) issue_v(ai, (u + AH) >> 1, (u + AH) & 1, vb[(u + AH) % VBD]);
                 if (LATE && last_app && h == 0 && g > 0) {    // the previous unit's results, parked in cf: both pieces of THIS unit are in flight
                     __builtin_amdgcn_sched_barrier(0);
                     store_unit(g - 1, cf[g - 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                finish_v(ai, g, h, vb[u & 1], lrq, lqq);
+                finish_v(ai, g, h, vb[u % VBD], lrq, lqq);
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     double a2[4];
@@ -423,8 +438,8 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
                     for (int p = 0; p < 2; ++p)
 #pragma unroll
                         for (int k4 = 0; k4 < 4; ++k4) {
-                            if (V4_ABLATE == 4) fr[p][ct][k4] += a2[k4] + vb[u & 1][k4][p];
-                            else fr[p][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[k4], vb[u & 1][k4][p], fr[p][ct], 0, 0, 0);
+                            if (V4_ABLATE == 4) fr[p][ct][k4] += a2[k4] + vb[u % VBD][k4][p];
+                            else fr[p][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[k4], vb[u % VBD][k4][p], fr[p][ct], 0, 0, 0);
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
