@@ -291,6 +291,10 @@ static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
         // ceil(blocks / 2) registers per lane and column: the smaller forms issue fewer multiply-adds per step on rows that hold
         // nothing (the geometry of a node is the same in every form: slot ln + 64 i = block (ln >> 5) + 2 i)
         int rpl = h->plan.RPL;
+        if (rpl == 8 && ((h->factor_nw4 >= 1 && a.level == 0) || h->factor_nw4 >= 2)) {      // A/B: 4 waves x 8 columns
+            hipLaunchKernelGGL((k_caqr_factor<8, 4>), grid, dim3(256), 0, h->stream, a);
+            return;
+        }
         if (a.level > 0 && groups == 1) {
             const int need = (a.nblocks + 1) / 2;
             const int fit = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 8));
@@ -1001,6 +1005,8 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (lk && lk[0] == '1') h->lookahead_forced = true;   // 1: for every paired sweep (tests)
         const char* fs = getenv("ENLSIP_GN_FUSE_SMALL");     // 0: J*Q1 and the one-tile panel factorisation as two launches (A/B)
         if (fs && fs[0] == '0') h->fuse_small = false;
+        const char* f4 = getenv("ENLSIP_GN_FACTOR_NW4");
+        if (f4) h->factor_nw4 = atoi(f4);
         const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");
         if (dm) h->debug_maxpan = atoi(dm);
         const char* ds = getenv("ENLSIP_GN_DEBUG_STAGE");
