@@ -369,7 +369,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     // ENLSIP_GN_STAGE_UPDATE and reported by enlsip_gn_get_update_totals
     auto other = [&](hipStream_t st, auto&& launch) -> int {
         hipEvent_t e1 = nullptr;
-        if (h->profiling) {
+        if (h->profiling && h->profile_all_updates) {
             if (h->oth_used + 2 > h->oth_ev.size()) {
                 for (int q = 0; q < 2; ++q) {
                     hipEvent_t e;
@@ -1086,6 +1086,7 @@ int enlsip_gn_synchronize(enlsip_gn_handle h) {
 int enlsip_gn_set_profiling(enlsip_gn_handle h, int enable) {
     if (!h) return -1;
     h->profiling = enable != 0;
+    h->profile_all_updates = enable >= 2;
     return 0;
 }
 

@@ -130,6 +130,7 @@ struct enlsip_gn_context {
 
     // profiling
     bool profiling = false;
+    bool profile_all_updates = false;   // enlsip_gn_set_profiling(h, 2): events around EVERY trailing-update launch (hundreds in a C4 sweep)
     hipEvent_t ev[8] = {};
     bool ev_ready = false;
     float stage_ms[ENLSIP_GN_STAGE_COUNT] = {};

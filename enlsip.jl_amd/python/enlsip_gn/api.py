@@ -263,8 +263,9 @@ class GNSolver:
         return p, bool(bad.value)
 
     # ---- instrumentation ------------------------------------------------------------------------
-    def set_profiling(self, on: bool):
-        self._chk(self._lib.enlsip_gn_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on: bool, all_updates: bool = False):
+        """HIP-event timing of the stages and the level-0 far updates; all_updates: every trailing-update launch (update_totals)."""
+        self._chk(self._lib.enlsip_gn_set_profiling(self._h, (2 if all_updates else 1) if on else 0))
 
     def stage_ms(self) -> dict:
         arr = (C.c_float * len(L.STAGE_NAMES))()

@@ -294,7 +294,10 @@ enum {
     ENLSIP_GN_STAGE_TOTAL = 5,
     ENLSIP_GN_STAGE_COUNT = 6
 };
-/* enable = 1 records events per stage (adds stream bubbles; off by default) */
+/* enable = 1 records events per stage and around the level-0 far updates (adds stream bubbles; off by default); enable = 2 also
+ * around every other trailing-update launch of the sweep (tree levels, second-panel columns): ENLSIP_GN_STAGE_UPDATE then is the
+ * sum over ALL update launches and enlsip_gn_get_update_totals reports them; with enable = 1 it is the far passes alone and the
+ * other update launches stay inside ENLSIP_GN_STAGE_PANEL (hundreds of event pairs would stretch a C4 sweep by ~3 %) */
 int enlsip_gn_set_profiling(enlsip_gn_handle h, int enable);
 int enlsip_gn_get_stage_ms(enlsip_gn_handle h, float* ms /* ENLSIP_GN_STAGE_COUNT */);
 /* average duration (ms) and count of the level-0 trailing-update launches of the last solve,

@@ -326,7 +326,7 @@ def test_update_table_and_stream_ceiling():
     for pair, launches in ((1, 4), (0, 7)):          # n2 = 224 = 7 full panels: pairs (0,1) (2,3) (4,5) + the seventh alone (d is its one trailing column)
         s = _solver_with_env(ENLSIP_GN_PAIR=pair)
         try:
-            s.set_profiling(True)
+            s.set_profiling(True, all_updates=True)
             s.solve_batched_dev(batch, m, n, t, J.data_ptr(), m, m * n, rx.data_ptr(), At.data_ptr(), n, n * t, cx.data_ptr(), dp=p.data_ptr())
             avg_ms, cnt, total = s.update_stats()
             table = s.update_table()
