@@ -414,7 +414,16 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         e = h->la_events[la_ev++];
         return 0;
     };
-    if (la) {
+    // The same idea for the PLAIN sweep of a chain-bound problem (a single C2 problem; a 32768-row shard of C4 where pairs do
+    // not pay): the factorisations of a panel (tile level and tree levels: they only read the panel's own columns) run first,
+    // its trailing updates are split into the next panel's 32 columns (this stream) and the rest (second stream), and the next
+    // panel's factorisations run beside that rest.  Order per panel k: F(k) -> E1 ; [wait E2(k-1)] near(k) ; second stream:
+    // wait E1, rest(k) -> E2.
+    // Measured (MI355X, round 4): it does NOT pay at the sizes it was meant for — a single C2 problem 4.18 -> 4.38 ms, four of them
+    // 4.59 -> 4.80 ms, a 32768 x 1024 shard 15.66 -> 15.63 ms: two event hand-overs per panel cost what the overlap of a ~25 us
+    // update with a ~75 us factor chain brings.  Kept behind ENLSIP_GN_LOOKAHEAD=1 (parity-tested in both sweeps), off by default.
+    const bool lap = !P.pair && use_mfma && h->lookahead && !mixed && h->debug_stage < 0 && npan >= 3 && h->lookahead_forced;
+    if (la || lap) {
         if (!h->stream2) {
             // lowest priority: the chain's small kernels on the main stream must not queue behind the thousands of workgroups
             // of the bulk update for a free CU slot
@@ -549,9 +558,52 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             continue;
         }
         // ---- one panel ----
-        if (int rcj = la_join()) return rcj;
         // last panel narrower than 32 with d as the only trailing column: d rides through the factor kernels
         const bool passenger = (ntrail == 1 && bwk < PB && kp_launch == n2_launch);
+        if (lap && !passenger && ntrail > 0) {
+            const auto& LV = P.panels[k].levels;
+            for (const LevelPlan& L : LV) {                      // every factorisation of the panel first
+                CaqrArgs a = caqr_args(h, k, L);
+                launch_factor(h, a, L.groups);
+            }
+            // updates of the levels, in order, on columns [sub0, sub0 + subn) of the trailing window (subn = 0: to its end)
+            auto upd = [&](int sub0, int subn, hipStream_t st) -> int {
+                const int ncw = (subn > 0 ? std::min(subn, ntrail - sub0) : ntrail - sub0);
+                const bool has_rhs = (sub0 + ncw == ntrail);       // the carried right-hand side is the window's last column
+                for (const LevelPlan& L : LV) {
+                    CaqrArgs a = caqr_args(h, k, L);
+                    a.sub0 = sub0; a.subn = subn;
+                    if (L.level == 0) {
+                        int rc = timed(btrail(k, ncw), st, [&] {
+                            if (has_rhs) update_l0(a, L, ncw, ncw, st);
+                            else launch_update_v4(h->plan.RPL, a, L.groups, ncw, (int)P.batch, st);
+                        });
+                        if (rc) return rc;
+                    } else {
+                        if (int rc = other(st, [&] { launch_update_v4(h->plan.RPL, a, L.groups, ncw, (int)P.batch, st); })) return rc;
+                    }
+                }
+                return 0;
+            };
+            if (ntrail <= PB) {                                    // nothing beyond the next panel's columns
+                if (int rcj = la_join()) return rcj;
+                if (int rc = upd(0, 0, sA)) return rc;
+            } else {
+                hipEvent_t e1, e2;
+                if (int rc = la_event(e1)) return rc;
+                if (int rc = la_event(e2)) return rc;
+                GN_HIP(hipEventRecord(e1, sA));                     // the panel's reflectors and T factors are complete
+                if (int rcj = la_join()) return rcj;                // the previous panel's rest covers the columns `near` touches
+                if (int rc = upd(0, PB, sA)) return rc;
+                GN_HIP(hipStreamWaitEvent(sB, e1, 0));
+                if (int rc = upd(PB, 0, sB)) return rc;
+                GN_HIP(hipEventRecord(e2, sB));
+                la_prev = e2;
+            }
+            ++k;
+            continue;
+        }
+        if (int rcj = la_join()) return rcj;
         for (const LevelPlan& L : P.panels[k].levels) {
             CaqrArgs a = caqr_args(h, k, L);
             a.npass = passenger ? 1 : 0;

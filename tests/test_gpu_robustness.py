@@ -263,15 +263,18 @@ def _solver_with_env(**env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pair", [1, 0])
 @pytest.mark.parametrize("m,n,t", [(9000, 200, 8), (20000, 330, 0), (5000, 96, 3)])
-def test_lookahead_sweep_matches_the_one_stream_sweep(m, n, t):
-    """Pairs with look-ahead forced (ENLSIP_GN_PAIR=1, ENLSIP_GN_LOOKAHEAD=1: the far update of a pair split over two streams with
-    events between them) against the oracle and against the same sweep on one stream: R0 and p must not depend on the schedule."""
+def test_lookahead_sweep_matches_the_one_stream_sweep(m, n, t, pair):
+    """Look-ahead forced (ENLSIP_GN_LOOKAHEAD=1) in the paired sweep (ENLSIP_GN_PAIR=1: the far update of a pair split over two
+    streams with events between them) and in the plain sweep (ENLSIP_GN_PAIR=0: every panel's trailing updates split into the next
+    panel's columns and the rest) against the oracle and against the same sweep on one stream: R0 and p must not depend on the
+    schedule."""
     J, rx, A, cx = synth.make_problem(6100 + m + n, m, n, t)
     ref = go.gn_subproblem(J, rx, A, cx)
     outs = []
     for la in (1, 0):
-        s = _solver_with_env(ENLSIP_GN_PAIR=1, ENLSIP_GN_LOOKAHEAD=la)
+        s = _solver_with_env(ENLSIP_GN_PAIR=pair, ENLSIP_GN_LOOKAHEAD=la)
         try:
             for _ in range(2):                  # twice on one handle: events and the second stream are reused
                 out = s.solve(J, rx, A, cx)
