@@ -51,7 +51,8 @@ typedef double v4_d2 __attribute__((ext_vector_type(2)));
 constexpr int V4_ABLATE = ENLSIP_V4_ABLATE;
 #ifdef ENLSIP_V4_STAMPS         // harness only (tests/microbench/update_bench.hip): phase stamps (100 MHz) of sample workgroups
 __device__ long long g_v4_stamps[8 * 8];
-#define V4_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 3 && blockIdx.y == 5 && (blockIdx.z & 31) == 7 && blockIdx.z < 256 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_v4_stamps[(blockIdx.z >> 5) * 8 + (i)] = wall_clock64(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ int g_v4_stamp_x = 3;      // group index (blockIdx.x) of the sampled workgroups (tree levels with one group: 0)
+#define V4_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == g_v4_stamp_x && blockIdx.y == 5 && (blockIdx.z & 31) == 7 && blockIdx.z < 256 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_v4_stamps[(blockIdx.z >> 5) * 8 + (i)] = wall_clock64(); } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define V4_STAMP(i) do { } while (0)
 #endif

@@ -194,6 +194,9 @@ int main(int argc, char** argv) {
         }
 #endif
     }
+#ifdef ENLSIP_V4_STAMPS
+    if (groups <= 3) { const int zero = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_v4_stamp_x), &zero, sizeof(int))); }
+#endif
     const int reps = 5;
     const double rows_k = (double)nblocks * 32;
     const double bytes = (double)batch * 8.0 * (2.0 * rows_k * ntrail + rows_k * 32);
