@@ -673,6 +673,22 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     const int G = (n2_launch + 1 + QD_CPW - 1) / QD_CPW;
     dim3 grid(G, (unsigned)P.batch);
     hipStream_t s = h->stream;
+    // Row-count statistics per block id (see SbArgs::rows_stat).  Every block is launched in up to three forms of the select /
+    // factor kernel and a problem runs in the one that fits its current row count; in a batch of similar problems two of the
+    // three launches of every block id find nothing to do — 24-40 us each at batch 384 (a launch of 384 x 512 threads that only
+    // reads its state), 1.3 ms of a C2 step.  The previous solve of the same shape on this handle tells which forms a block id
+    // needs; a problem that a skipped form would have served simply makes no step in that block id, the end-of-stage check
+    // sees it and the stage goes on WITHOUT hints, so the result never depends on them.
+    {
+        int rc = grow(h, h->sb_stat, 2 * SB_STAT_BLKS * sizeof(int));
+        if (rc) return rc;
+        if (!h->h_sb_stat) GN_HIP(hipHostMalloc((void**)&h->h_sb_stat, 2 * SB_STAT_BLKS * sizeof(int), hipHostMallocDefault));
+        GN_HIP(hipMemsetAsync(h->sb_stat.p, 0, 2 * SB_STAT_BLKS * sizeof(int), s));
+        a.rows_stat = (int*)h->sb_stat.p;
+    }
+    bool hints = h->sb_form_hints && h->sb_rows_kp == kp_launch && h->sb_rows_batch == P.batch && !h->sb_rows_max.empty();
+    const bool hinted = hints;
+    bool fell_back = false;
     hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, s, q);
     hipLaunchKernelGGL(k_sb_reset, dim3(((unsigned)P.n + 255) / 256, (unsigned)P.batch), dim3(256), 0, s, a, (int)P.n);
     dim3 ugrid((n2_launch + 1 + SB_UCW - 1) / SB_UCW, (unsigned)P.batch);
@@ -691,17 +707,26 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
             // forms are no longer launched once kp_launch - it fits a smaller one.
             const int rows_max = kp_launch - it;
             const dim3 fg((unsigned)P.batch);
-            if (rows_max > 256) {
+            bool big = rows_max > 256, med = rows_max > 128, small = true;
+            if (hints && it < (int)h->sb_rows_max.size() && h->sb_rows_max[it] > 0) {
+                // what the previous solve saw at this block id, widened by a block's worth of steps either way
+                const int lo = h->sb_rows_min[it] - 32, hi = h->sb_rows_max[it] + 32;
+                big = big && hi > 256;
+                med = med && hi > 128 && lo <= 256;
+                small = lo <= 128;
+            }
+            if (big) {
                 if (kp_launch <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8, 4>), fg, dim3(512), 0, s, a);
                 else hipLaunchKernelGGL((k_sb_factor_reg<8, 8, 4>), fg, dim3(512), 0, s, a);
             }
-            if (rows_max > 128) hipLaunchKernelGGL((k_sb_factor_reg<4, 8, 2>), fg, dim3(512), 0, s, a);
-            hipLaunchKernelGGL((k_sb_factor_reg<2, 8, 0>), fg, dim3(512), 0, s, a);
+            if (med) hipLaunchKernelGGL((k_sb_factor_reg<4, 8, 2>), fg, dim3(512), 0, s, a);
+            if (small) hipLaunchKernelGGL((k_sb_factor_reg<2, 8, 0>), fg, dim3(512), 0, s, a);
             hipLaunchKernelGGL(k_sb_update_blk, ugrid, dim3(256), 0, s, a);
         }
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(hinfo, h->sbInfo, (size_t)P.batch * sizeof(SbInfo), hipMemcpyDeviceToHost, s));
         GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)P.batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
+        GN_HIP(hipMemcpyAsync(h->h_sb_stat, h->sb_stat.p, 2 * SB_STAT_BLKS * sizeof(int), hipMemcpyDeviceToHost, s));
         GN_HIP(hipStreamSynchronize(s));
         bool done = true;
         for (long long k = 0; k < P.batch; ++k)
@@ -710,8 +735,27 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
             int used = 0;
             for (long long k = 0; k < P.batch; ++k) used = std::max(used, hinfo[k].blk + 1);
             h->sb_hint = used + 1;
+            // statistics of this solve = hints of the next one (only of a stage that ran on hints it could trust or on none:
+            // a block id in which some problem found no form to run in shows smaller counts than it should)
+            if (hinted && fell_back) {      // the hints misled this stage: its statistics are incomplete; the next solve runs without
+                h->sb_rows_max.clear();
+                h->sb_rows_min.clear();
+                h->sb_rows_kp = -1;
+                break;
+            }
+            const int nb = std::min(it, SB_STAT_BLKS);
+            h->sb_rows_max.assign(nb, 0);
+            h->sb_rows_min.assign(nb, 0);
+            for (int b = 0; b < nb; ++b) {
+                h->sb_rows_max[b] = h->h_sb_stat[b];
+                h->sb_rows_min[b] = h->h_sb_stat[b] > 0 ? SB_STAT_OFF - h->h_sb_stat[SB_STAT_BLKS + b] : 0;
+            }
+            h->sb_rows_kp = kp_launch;
+            h->sb_rows_batch = P.batch;
             break;
         }
+        hints = false;          // somebody is not done: the rest of the stage launches every form
+        fell_back = true;
         chunk = 4;
     }
     hipLaunchKernelGGL(k_qd_assemble, grid, dim3(256), 0, s, q);
@@ -1057,6 +1101,8 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (lk && lk[0] == '1') h->lookahead_forced = true;   // 1: for every paired sweep (tests)
         const char* fs = getenv("ENLSIP_GN_FUSE_SMALL");     // 0: J*Q1 and the one-tile panel factorisation as two launches (A/B)
         if (fs && fs[0] == '0') h->fuse_small = false;
+        const char* fh = getenv("ENLSIP_GN_SB_FORM_HINTS");   // 0: every block of the blocked pivoted QR in all of its forms (A/B)
+        if (fh && fh[0] == '0') h->sb_form_hints = false;
         const char* f4 = getenv("ENLSIP_GN_FACTOR_NW4");
         if (f4) h->factor_nw4 = atoi(f4);
         const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");
@@ -1108,6 +1154,8 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     tsqr_drop_comm(h);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_sbinfo) (void)hipHostFree(h->h_sbinfo);
+    if (h->h_sb_stat) (void)hipHostFree(h->h_sb_stat);
+    if (h->sb_stat.p) (void)hipFree(h->sb_stat.p);
     if (h->ev_ready)
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->upd_ev) (void)hipEventDestroy(e);

@@ -78,6 +78,14 @@ struct enlsip_gn_context {
     int *qdChosen = nullptr, *qdPos = nullptr, *qdColat = nullptr;
     void* qdCand = nullptr;
     unsigned* small = nullptr;
+    // row counts the blocks of the previous blocked QRCP started with (min / max over the problems, by block id), valid for
+    // sb_rows_kp == kp_launch and the same batch: which forms of the select / factor kernel a block id needs
+    std::vector<int> sb_rows_min, sb_rows_max;
+    int sb_rows_kp = -1;
+    long long sb_rows_batch = -1;
+    gn::DevBuf sb_stat;          // device statistics (2 x SB_STAT_BLKS ints)
+    int* h_sb_stat = nullptr;    // pinned mirror
+    bool sb_form_hints = true;   // ENLSIP_GN_SB_FORM_HINTS=0: every block id in all three forms (A/B)
     int sb_hint = 0;             // blocks the previous blocked QRCP needed (+1): size of the first launch chunk
     double* sbT = nullptr;       // per problem: T factor of the current QRCP block (32 x 32)
     void* sbInfo = nullptr;      // SbInfo per problem (device)

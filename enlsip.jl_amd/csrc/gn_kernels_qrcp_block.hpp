@@ -50,7 +50,13 @@ struct SbArgs {
     double* Tsb;      long long sTsb;   // per problem: dlarft T (32 x 32, column-major) of the last block's reflectors
     int* act;         long long sAct;   // per problem: compact list of the columns the block update touches
     long long* dbg;   // optional (diagnostic builds): 8 realtime stamps per block of problem prob0
+    // per handle: [blkid] = max over the problems of the row count kp - j0 a block started with, [SB_STAT_BLKS + blkid] =
+    // SB_STAT_OFF - min of it.  The host reads them back with the end-of-stage check and launches, in the NEXT solve of the same
+    // shape, only the forms of the select / factor kernel whose row ranges they touch (run_qrcp_block).
+    int* rows_stat;
 };
+constexpr int SB_STAT_BLKS = 1024;     // block ids (a block makes at least one step: kp <= 512 here)
+constexpr int SB_STAT_OFF = 1 << 20;
 
 // reset of the per-problem block state; runs after k_qd_init
 __global__ void k_sb_reset(SbArgs a, int n) {

@@ -70,6 +70,10 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
     if (info->blk == a.blkid) return;                     // a larger form has just done this block's steps (and advanced j0)
     if (rows > 64 * RPL) return;                          // served by a larger form
     if (RPL_LOW > 0 && rows <= 64 * RPL_LOW) return;      // served by the smaller form launched beside this one
+    if (tid == 0 && a.rows_stat && a.blkid < SB_STAT_BLKS) {      // row-count statistics of this block id (launch hints of the next solve)
+        atomicMax(a.rows_stat + a.blkid, rows);
+        atomicMax(a.rows_stat + SB_STAT_BLKS + a.blkid, SB_STAT_OFF - rows);
+    }
     double* M = a.q.M + prob * a.q.sM;
     double* vn1 = a.q.vn1 + prob * a.q.sVn;
     double* vn2 = a.q.vn2 + prob * a.q.sVn;
