@@ -288,6 +288,37 @@ def test_lookahead_sweep_matches_the_one_stream_sweep(m, n, t, pair):
 
 
 @pytest.mark.gpu
+def test_blocked_qrcp_form_hints_never_change_a_result():
+    """The blocked pivoted QR of R0 launches, per block id, only the forms of its select / factor kernel that the PREVIOUS solve of the
+    same shape on the handle needed (run_qrcp_block, SbArgs::rows_stat).  Problems of one shape but very different block structure,
+    one after the other on ONE handle — random (long blocks), graded spectrum (norm recomputations, short blocks), rank deficient J
+    (the stage ends early), random again — so that every solve starts on hints that do not fit it: each must match the oracle and
+    a fresh handle that has no hints (bit for bit: the same kernels run on the same numbers, only empty launches differ)."""
+    from enlsip_gn import GNSolver
+    m, n, t = 1500, 330, 30            # kp = 300: register forms for 448 / 256 / 128 rows all in use
+    gens = [synth.make_problem, synth.make_graded_J, synth.make_rank_deficient_J, synth.make_problem, synth.make_graded_J]
+    probs = [g(7700 + i, m, n, t) for i, g in enumerate(gens)]
+    one = GNSolver(device=0)
+    try:
+        for i, (J, rx, A, cx) in enumerate(probs):
+            ref = go.gn_subproblem(J, rx, A, cx)
+            for _ in range(2):                       # the second time the hints DO fit
+                out = one.solve(J, rx, A, cx)
+                fresh = _solver_with_env(ENLSIP_GN_SB_FORM_HINTS=0)
+                try:
+                    base = fresh.solve(J, rx, A, cx)
+                finally:
+                    fresh.close()
+                assert np.array_equal(out.p, base.p) and np.array_equal(out.jpvtJ2, base.jpvtJ2) and out.rankJ2 == base.rankJ2, i
+                assert (out.rankA, out.rankJ2, out.code) == (ref.rankA, ref.rankJ2, ref.code), i
+                r = ref.rankJ2
+                assert np.array_equal(out.jpvtJ2[:r], ref.jpvtJ2[:r]), i
+                assert rel(out.p, ref.p) <= (1e-9 if gens[i] is synth.make_problem else 1e-5), i
+    finally:
+        one.close()
+
+
+@pytest.mark.gpu
 def test_fused_small_kernel_matches_the_two_launch_form():
     """One-tile problems with one narrow panel (C5's shape and neighbours): J*Q1 + panel in one launch (default) and as two launches
     (ENLSIP_GN_FUSE_SMALL=0) give the same factors, bit for bit — the fused kernel runs the same factorisation body on the same
