@@ -75,6 +75,16 @@ __device__ __forceinline__ double wave_allsum(double x) {
     return xor32_sum(x);
 }
 
+// All-reduce inside each 32-lane half of the wave (two problems per wave: gn_kernels_final_small.hpp): wave_allsum without its
+// last level.
+__device__ __forceinline__ double half_allsum(double x) {
+    x += dpp_f64<0xB1>(x);
+    x += dpp_f64<0x4E>(x);
+    x += dpp_f64<0x141>(x);
+    x += dpp_f64<0x140>(x);
+    return xor16_sum(x);
+}
+
 // Eight simultaneous wave all-reduces ("transposed" butterfly): at every DPP level a lane hands
 // half of its partial sums to its partner and keeps the other half, so 8 -> 4 -> 2 -> 1 values are
 // moved instead of 8 each time.  Partner order row_mirror (i^15), row_half_mirror (i^7),

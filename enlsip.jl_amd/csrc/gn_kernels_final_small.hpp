@@ -97,21 +97,26 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : (
 
     // ---- dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]: lane r carries row r of the right-hand side ------------------------
     double zw = (ln < dimJ2 && ln < kp) ? tmp[ln * 65 + n2] : 0.0;
+    // lane i divides ITS diagonal entry once, before the loop: a division on the critical path of every step otherwise
+    const double dmine = (ln < kp && ln <= n2) ? tmp[ln * 65 + lp] : 1.0;
+    const double rinv = 1.0 / dmine;
+    if ((ln < dimJ2 && ln < kp) && dmine == 0.0) status |= 1;
     for (int i = (dimJ2 < kp ? dimJ2 : kp) - 1; i >= 0; --i) {
         const int li = __builtin_amdgcn_readlane(lp, i);
-        const double dkk = tmp[i * 65 + li];
-        if (dkk == 0.0) status |= 1;
-        const double yi = wave_bcast(zw, i) / dkk;
+        const double yi = wave_bcast(zw, i) * wave_bcast(rinv, i);
         if (ln == i) zw = yi;
         if (ln < i) zw -= tmp[ln * 65 + li] * yi;
     }
+    status = __any(status) ? 1 : 0;
     GN_PS_STAMP(4);
     // y = [p1 ; p2],  p2[pJ[i]-1] = (i < dimJ2 ? dp2[i] : 0)
     for (int i = ln; i < rankA; i += WAVE) pbuf[i] = p1[i];
     if (ln < n2) pbuf[rankA + lp] = (ln < dimJ2) ? zw : 0.0;
     // p = F_A.Q * y
     wave_mem_sync();
-    wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);
+    if (n <= 64) wave_apply_reflectors_reg<false, 1>(FA, n, tauA, kA, n, pbuf);      // reflectors prefetched, tau in one request
+    else if (n <= 128) wave_apply_reflectors_reg<false, 2>(FA, n, tauA, kA, n, pbuf);
+    else wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);
     wave_mem_sync();
     GN_PS_STAMP(5);
     if (a.p_out)
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : (
 // other with all of its lanes as workers (back substitution, p = F_A.Q [p1; p2], output records), exactly as k_pivot_small does.
 // LDS (doubles): tmp[kpm * 65] vbuf[128] dg[128] lpos[64 ints] pbuf[nv]
 // ---------------------------------------------------------------------------------------------------------------------------------
-inline size_t final_small2_lds_bytes(int kpm, int nv) { return (size_t)(kpm * 65 + 128 + 128 + 32 + nv + 8) * 8; }
+inline size_t final_small2_lds_bytes(int kpm, int nv) { return (size_t)(kpm * 65 + 128 + 128 + 32 + 2 * nv + 8) * 8; }   // pbuf: one per half
 
 __global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) {      // 3 waves per SIMD: 168 registers
     constexpr int NR = 32;
@@ -205,6 +210,124 @@ __global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) 
     if (kmax > 0) wave_qrcp2<NR>(x, q, kmax, ln, mypos);
     wave_mem_sync();
 
+    // ---- n <= 128: both problems finish SIDE BY SIDE, each on its own 32 lanes (the serial form below ran this tail — upper parts,
+    //      rank, back substitution, Q1 y, outputs: about as long as the 28 pivot steps of a C5 problem — twice per wave) ------------
+    if (n <= 128) {
+        const bool act = have && ok;
+        const size_t pb = (size_t)prob_l;
+        ProbState* stp = a.state + pb;
+        long long* jpvtJ = a.jpvtJ + pb * a.sJJ;
+        const double* FA = a.FA + pb * a.sFA;
+        const double* tauA = a.tauA + pb * a.sTauA;
+        const double* p1 = a.p1 + pb * a.sP1;
+        const double* bvec = a.bvec + pb * a.sB;
+        const double* dgh = dg + 2 * hb;
+        int* lposh = lpos + hb;
+        double* pbufh = pbuf + half * a.nv;
+        int status = 0;
+        if (act && lh < n2) jpvtJ[mypos] = lh + 1;
+        wave_mem_sync();
+        if (act && lh <= n2) lposh[mypos] = lh;
+        wave_mem_sync();
+        const int lp = (act && lh <= n2) ? lposh[lh] : 0;        // lane i of the half: the column that sits at position i
+        const int n2a = act ? n2 : -1;
+        const int n2m = max(__builtin_amdgcn_readlane(n2a, 0), __builtin_amdgcn_readlane(n2a, 32));
+        for (int P = 0; P <= n2m; ++P) {                           // upper parts of the factor columns (and the carried one)
+            const bool on = P <= n2a;
+            const int src = on ? lposh[P] : 0;
+            if (on && lh < kp && lh <= P) Rt[lh + (size_t)P * ldr] = tmp[lh * 65 + hb + src];
+        }
+        int rankJ2 = 0;
+        {
+            const double d0 = (kp > 0) ? fabs(dgh[0]) : 0.0;
+            const double tol = d0 * sqrt((double)(kp > 0 ? kp : 1)) * a.eps_rank;
+            const bool fail = (lh < kp) && !(fabs(dgh[lh < kp ? lh : 0]) > tol);
+            const unsigned mh = (unsigned)(__ballot(fail) >> hb);
+            if (kp > 0 && !(d0 < a.eps_rank)) rankJ2 = mh ? (int)__builtin_ctz(mh) : kp;
+        }
+        int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
+        dimJ2 = dimJ2 < kp ? dimJ2 : kp;
+        if (!act) dimJ2 = 0;
+        // dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]: lane r of the half carries row r of the right-hand side
+        double zw = (lh < dimJ2) ? tmp[lh * 65 + hb + n2] : 0.0;
+        const double dmine = (lh < kp && lh <= n2 && act) ? tmp[lh * 65 + hb + lp] : 1.0;     // one division per row, before the loop
+        const double rinv = 1.0 / dmine;
+        if (lh < dimJ2 && dmine == 0.0) status |= 1;
+        const int dmx = max(__builtin_amdgcn_readlane(dimJ2, 0), __builtin_amdgcn_readlane(dimJ2, 32));
+        for (int i = dmx - 1; i >= 0; --i) {
+            const bool on = i < dimJ2;
+            const int li = on ? lposh[i] : 0;
+            const double y0 = readlane_f64(zw, i) * readlane_f64(rinv, i);
+            const double y1 = readlane_f64(zw, 32 + i) * readlane_f64(rinv, 32 + i);
+            const double yi = half ? y1 : y0;
+            if (on && lh == i) zw = yi;
+            if (on && lh < i) zw -= tmp[lh * 65 + hb + li] * yi;
+        }
+        // y = [p1 ; p2],  p2[pJ[i]-1] = (i < dimJ2 ? dp2[i] : 0)
+        const int rAa = act ? rankA : 0;
+        const int rAm = max(__builtin_amdgcn_readlane(rAa, 0), __builtin_amdgcn_readlane(rAa, 32));
+        for (int i = lh; i < rAm; i += 32)
+            if (i < rAa) pbufh[i] = p1[i];
+        if (act && lh < n2) pbufh[rankA + lp] = (lh < dimJ2) ? zw : 0.0;
+        wave_mem_sync();
+        {   // p = F_A.Q * y, per half: lane lh owns entries lh + 32 i of its problem's vector; reflectors prefetched one ahead
+            constexpr int RH = 4;
+            double xr[RH], vn[RH];
+#pragma unroll
+            for (int i = 0; i < RH; ++i) xr[i] = (act && lh + 32 * i < n) ? pbufh[lh + 32 * i] : 0.0;
+            auto fetch = [&](int j, double (&v)[RH]) {
+#pragma unroll
+                for (int i = 0; i < RH; ++i) {
+                    const int r = lh + 32 * i;
+                    v[i] = (act && r > j && r < n) ? FA[r + (size_t)j * n] : 0.0;
+                }
+            };
+            const double tl = (act && lh < kA) ? tauA[lh] : 0.0;          // kA <= 32 reflectors here? no: up to 63 -> second word below
+            const double tl2 = (act && lh + 32 < kA) ? tauA[lh + 32] : 0.0;
+            if (kA > 0) fetch(kA - 1, vn);
+            for (int sidx = 0; sidx < kA; ++sidx) {
+                const int j = kA - 1 - sidx;
+                double v[RH];
+#pragma unroll
+                for (int i = 0; i < RH; ++i) v[i] = (lh + 32 * i == j) ? 1.0 : vn[i];
+                if (sidx + 1 < kA) fetch(j - 1, vn);
+                const double t0 = (j < 32) ? readlane_f64(tl, j) : readlane_f64(tl2, j - 32);
+                const double t1 = (j < 32) ? readlane_f64(tl, 32 + j) : readlane_f64(tl2, j);
+                const double tj = half ? t1 : t0;
+                double dot = 0.0;
+#pragma unroll
+                for (int i = 0; i < RH; ++i) dot += v[i] * xr[i];
+                dot = (tj != 0.0) ? half_allsum(dot) * tj : 0.0;               // tj = 0 (no reflector / inactive half): nothing happens
+#pragma unroll
+                for (int i = 0; i < RH; ++i) xr[i] -= dot * v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < RH; ++i)
+                if (act && lh + 32 * i < n) pbufh[lh + 32 * i] = xr[i];
+        }
+        wave_mem_sync();
+        if (act) {
+            if (a.p_out)
+                for (int i = lh; i < n; i += 32) a.p_out[pb * a.sPo + i] = pbufh[i];
+            if (a.b_out)
+                for (int i = lh; i < t; i += 32) a.b_out[pb * a.sBo + i] = bvec[i];
+            if (a.d_out)
+                for (int i = lh; i < m; i += 32)
+                    a.d_out[pb * a.sDo + i] = (i < kp) ? tmp[i * 65 + hb + n2] : W[i + (size_t)n * ldw];
+            if (a.jA_out)
+                for (int i = lh; i < t; i += 32) a.jA_out[pb * a.sJAo + i] = a.jpvtA[pb * a.sJA + i];
+            if (a.jL_out)
+                for (int i = lh; i < kA; i += 32) a.jL_out[pb * a.sJLo + i] = a.jpvtL[pb * a.sJL + i];
+            if (a.jJ_out && lh < n2) a.jJ_out[pb * a.sJJo + mypos] = lh + 1;
+        }
+        const int st0 = __any(status && !half) ? 1 : 0, st1 = __any(status && half) ? 1 : 0;
+        if (act && lh == 0) {
+            stp->rankJ2 = rankJ2;
+            stp->dimJ2 = dimJ2;
+            stp->status |= half ? st1 : st0;
+        }
+        return;
+    }
     // ---- the wave finishes problem 0, then problem 1 -----------------------------------------------------------------------------
     for (int hsel = 0; hsel < 2; ++hsel) {
         const int hbu = 32 * hsel;
@@ -247,19 +370,23 @@ __global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) 
         dimJ2 = dimJ2 < kpu ? dimJ2 : kpu;
         // dp2 = U(Rt[1:dimJ2,1:dimJ2]) \ d[1:dimJ2]: lane r carries row r of the right-hand side
         double zw = (ln < dimJ2) ? tmp[ln * 65 + hbu + n2u] : 0.0;
+        const double dmine = (ln < kpu && ln <= n2u) ? tmp[ln * 65 + hbu + lp] : 1.0;     // one division per row, before the loop
+        const double rinv = 1.0 / dmine;
+        if (ln < dimJ2 && dmine == 0.0) status |= 1;
         for (int i = dimJ2 - 1; i >= 0; --i) {
             const int li = lpos[i];
-            const double dkk = tmp[i * 65 + hbu + li];
-            if (dkk == 0.0) status |= 1;
-            const double yi = wave_bcast(zw, i) / dkk;
+            const double yi = wave_bcast(zw, i) * wave_bcast(rinv, i);
             if (ln == i) zw = yi;
             if (ln < i) zw -= tmp[ln * 65 + hbu + li] * yi;
         }
+        status = __any(status) ? 1 : 0;
         // y = [p1 ; p2],  p2[pJ[i]-1] = (i < dimJ2 ? dp2[i] : 0)
         for (int i = ln; i < rAu; i += WAVE) pbuf[i] = p1[i];
         if (inh && ln < n2u) pbuf[rAu + lp] = (ln < dimJ2) ? zw : 0.0;
         wave_mem_sync();
-        wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);      // p = F_A.Q * y
+        if (n <= 64) wave_apply_reflectors_reg<false, 1>(FA, n, tauA, kA, n, pbuf);      // p = F_A.Q * y
+        else if (n <= 128) wave_apply_reflectors_reg<false, 2>(FA, n, tauA, kA, n, pbuf);
+        else wave_apply_reflectors<false>(FA, n, tauA, kA, n, pbuf);
         wave_mem_sync();
         if (a.p_out)
             for (int i = ln; i < n; i += WAVE) a.p_out[(size_t)prob * a.sPo + i] = pbuf[i];

@@ -301,13 +301,16 @@ __device__ void wave_apply_reflectors_reg(const double* __restrict__ F, int ld, 
         }
     };
     if (k > 0) fetch(TRANS ? 0 : k - 1, vn);
+    // tau of up to 64 reflectors in one request (lane j holds tau[j]); a load per reflector inside the loop is an exposed L2 round
+    // trip each (the one-wave-per-problem kernels apply Q1 to one vector: their tail is these chains)
+    const double tl = (ln < k && ln < 64) ? tau[ln] : 0.0;
     for (int s = 0; s < k; ++s) {
         const int j = TRANS ? s : k - 1 - s;
         double v[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) v[i] = (ln + 64 * i == j) ? 1.0 : vn[i];
         if (s + 1 < k) fetch(TRANS ? s + 1 : k - 2 - s, vn);
-        const double tj = tau[j];
+        const double tj = (j < 64) ? readlane_f64(tl, j) : tau[j];
         if (tj == 0.0) continue;
         double dot = 0.0;
 #pragma unroll
