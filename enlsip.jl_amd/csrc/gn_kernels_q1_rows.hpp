@@ -67,11 +67,74 @@ __global__ __launch_bounds__(256, (NMAX == 32 && ENLSIP_JR_OCC) ? ENLSIP_JR_OCC 
     W[row + (size_t)n * ldw] = live ? (-ds - rx[row]) : 0.0;
 }
 
+// Two lanes per row for 32 < n <= 64 (C3): lane l < 32 of a wave owns columns 0..31 of row l, lane l + 32 columns 32..63 of the
+// SAME row; a dot product is two half sums joined by one cross-half add.  Half the registers per lane (the one-lane form
+// needs 255 and runs at two workgroups per CU: the kernel moves 0.54 GB at 2.8 TB/s because too few loads are in flight), so
+// four workgroups per CU; the row data is requested before the reflectors are staged, rx with it.
+template <int dummy = 0>
+__global__ __launch_bounds__(256, 3) void k_jq1_rows2(JQ1Args a) {
+    constexpr int NH = 32;                                                // columns per lane
+    __shared__ __attribute__((aligned(16))) double Vs[Q1R_MAXK * 64];    // Vs[k][c] = v_k[c] (unit diagonal, zeros above)
+    __shared__ double taus[Q1R_MAXK];
+    __shared__ double p1s[64];
+    const int n = a.n, m = a.m, kA = a.kA, ldw = a.ldw;
+    const int prob = blockIdx.y + a.prob0;
+    const double* Jin = a.J + prob * a.strideJ;
+    const double* rx = a.rx + prob * a.stride_rx;
+    const double* FA = a.FA + prob * a.sFA;
+    const double* TA = a.TA + prob * a.sTA;
+    const double* p1 = a.p1 + prob * a.sP1;
+    double* W = a.W + prob * a.sW;
+    const int rankA = a.state[prob].rankA;
+    const int tid = threadIdx.x, ln = tid & 63, w = tid >> 6;
+    const int half = ln >> 5;                                            // which 32 columns
+    const int row = blockIdx.x * 128 + 32 * w + (ln & 31);
+    const bool inrange = row < ldw, live = row < m;
+    const int c0 = NH * half;
+
+    // addresses = uniform base of column c + ONE 32-bit lane offset (row and column half): no 64-bit address per column
+    const unsigned joff = (unsigned)(((size_t)row + (size_t)c0 * a.ldj) * 8), woff = (unsigned)(((size_t)row + (size_t)c0 * ldw) * 8);
+    double x[NH];
+#pragma unroll
+    for (int c = 0; c < NH; ++c)
+        x[c] = (live && c0 + c < n) ? __builtin_nontemporal_load((const double*)((const char*)(Jin + (size_t)c * a.ldj) + joff)) : 0.0;
+    const double rxv = (live && half == 0) ? rx[row] : 0.0;
+    for (int e = tid; e < kA * 64; e += 256) {
+        const int k = e >> 6, c = e & 63;
+        double v = 0.0;
+        if (c < n) v = (c > k) ? FA[c + (size_t)k * n] : (c == k ? 1.0 : 0.0);
+        Vs[e] = v;
+    }
+    if (tid < kA) taus[tid] = TA[tid + tid * KBLK];       // dlarft: diag(T) = tau
+    if (tid < 64) p1s[tid] = (tid < rankA) ? p1[tid] : 0.0;
+    __syncthreads();
+    if (!inrange) return;
+    for (int k = 0; k < kA; ++k) {
+        const double* vk = Vs + k * 64 + c0;
+        double dot = 0.0;
+#pragma unroll
+        for (int c = 0; c < NH; ++c) dot += x[c] * vk[c];
+        const double s = taus[k] * xor32_sum(dot);
+#pragma unroll
+        for (int c = 0; c < NH; ++c) x[c] -= s * vk[c];
+    }
+    double ds = 0.0;
+#pragma unroll
+    for (int c = 0; c < NH; ++c) ds += x[c] * p1s[c0 + c];
+    ds = xor32_sum(ds);
+#pragma unroll
+    for (int c = 0; c < NH; ++c)
+        if (c0 + c < n) *(double*)((char*)(W + (size_t)c * ldw) + woff) = x[c];
+    if (half == 0) W[row + (size_t)n * ldw] = live ? (-ds - rxv) : 0.0;
+}
+
 // Returns false when the shape is outside this kernel's range (the caller falls through to the compact-WY kernels).
 inline bool launch_jq1_rows(const JQ1Args& a, int batch, hipStream_t s) {
     if (a.n > 64 || a.kA > Q1R_MAXK) return false;
     const dim3 grid((a.ldw + 255) / 256, batch);
+    static const bool two = !(getenv("ENLSIP_GN_JQ1_ROWS2") && getenv("ENLSIP_GN_JQ1_ROWS2")[0] == '0');      // A/B switch
     if (a.n <= 32) hipLaunchKernelGGL(k_jq1_rows<32>, grid, dim3(256), 0, s, a);
+    else if (two && a.ldj < (1 << 23) && a.ldw < (1 << 23)) hipLaunchKernelGGL(k_jq1_rows2<0>, dim3((a.ldw + 127) / 128, batch), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_jq1_rows<64>, grid, dim3(256), 0, s, a);
     return true;
 }
