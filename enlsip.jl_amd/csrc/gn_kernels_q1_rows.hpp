@@ -33,6 +33,13 @@ __global__ __launch_bounds__(256, (NMAX == 32 && ENLSIP_JR_OCC) ? ENLSIP_JR_OCC 
     const int rankA = a.state[prob].rankA;
     const int tid = threadIdx.x;
 
+    // the row and its rx entry are requested first: the staging of the reflectors runs beside them, not in front of them
+    const int row = blockIdx.x * 256 + tid;
+    const bool live = row < m;
+    double x[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) x[c] = (live && c < n) ? __builtin_nontemporal_load(&Jin[row + (size_t)c * a.ldj]) : 0.0;
+    const double rxv = live ? rx[row] : 0.0;
     for (int e = tid; e < kA * NMAX; e += 256) {
         const int k = e / NMAX, c = e % NMAX;
         double v = 0.0;
@@ -42,13 +49,7 @@ __global__ __launch_bounds__(256, (NMAX == 32 && ENLSIP_JR_OCC) ? ENLSIP_JR_OCC 
     if (tid < kA) taus[tid] = TA[tid + tid * KBLK];       // dlarft: diag(T) = tau
     if (tid < NMAX) p1s[tid] = (tid < rankA) ? p1[tid] : 0.0;
     __syncthreads();
-
-    const int row = blockIdx.x * 256 + tid;
     if (row >= ldw) return;
-    const bool live = row < m;
-    double x[NMAX];
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c) x[c] = (live && c < n) ? __builtin_nontemporal_load(&Jin[row + (size_t)c * a.ldj]) : 0.0;
     for (int k = 0; k < kA; ++k) {
         const double* vk = Vs + k * NMAX;
         double dot = 0.0;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256, (NMAX == 32 && ENLSIP_JR_OCC) ? ENLSIP_JR_OCC 
 #pragma unroll
     for (int c = 0; c < NMAX; ++c)
         if (c < n) W[row + (size_t)c * ldw] = x[c];
-    W[row + (size_t)n * ldw] = live ? (-ds - rx[row]) : 0.0;
+    W[row + (size_t)n * ldw] = live ? (-ds - rxv) : 0.0;
 }
 
 // Two lanes per row for 32 < n <= 64 (C3): lane l < 32 of a wave owns columns 0..31 of row l, lane l + 32 columns 32..63 of the

@@ -41,6 +41,14 @@ __global__ __launch_bounds__(256, 4) void k_jq1_factor_small(JQ1Args q, CaqrArgs
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
 
     // ---- J Q1 and d_temp, a lane per row (k_jq1_rows) --------------------------------------------------------------------
+    // the row and its rx entry are requested FIRST: the staging of the reflectors (a global round trip and a barrier) then runs
+    // beside them instead of in front of them
+    const int row = tid;                                   // m <= 256: one workgroup holds every row
+    const bool live = row < m;
+    double xr[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) xr[c] = (live && c < n) ? __builtin_nontemporal_load(&Jin[row + (size_t)c * q.ldj]) : 0.0;
+    const double rxv = live ? rx[row] : 0.0;
     for (int e = tid; e < kA * NMAX; e += 256) {
         const int k = e / NMAX, c = e % NMAX;
         double v = 0.0;
@@ -50,11 +58,6 @@ __global__ __launch_bounds__(256, 4) void k_jq1_factor_small(JQ1Args q, CaqrArgs
     if (tid < kA) taus[tid] = TA[tid + tid * KBLK];       // dlarft: diag(T) = tau
     if (tid < NMAX) p1s[tid] = (tid < rankA) ? p1[tid] : 0.0;
     __syncthreads();
-    const int row = tid;                                   // m <= 256: one workgroup holds every row
-    const bool live = row < m;
-    double xr[NMAX];
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c) xr[c] = (live && c < n) ? __builtin_nontemporal_load(&Jin[row + (size_t)c * q.ldj]) : 0.0;
     for (int k = 0; k < kA; ++k) {
         const double* vk = Vs + k * NMAX;
         double dot = 0.0;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256, 4) void k_jq1_factor_small(JQ1Args q, CaqrArgs
     double ds = 0.0;
 #pragma unroll
     for (int c = 0; c < NMAX; ++c) ds += xr[c] * p1s[c];
-    const double dtemp = live ? (-ds - rx[row]) : 0.0;
+    const double dtemp = live ? (-ds - rxv) : 0.0;
     // J1 stays in W for the consumers of J Q1 (multiplier estimates, re-solve); rankA <= kA <= 16
     if (row < ldw) {
 #pragma unroll
