@@ -65,9 +65,13 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_CS_OCC) ? ENLSIP_CS_OCC : (
     const int lp = (ln < t) ? lpos[ln] : 0;          // lane i: the lane (= column of A') that sits at position i
     wave_qrcp_store_upper(q, ln, lp, t, FA, n);
     if (kA > 0) {
-        // block T factor (one block: kA <= 63), zero outside the upper triangle
+        // block T factor (one block: kA <= 63), zero outside the upper triangle.  The compact-WY kernels of J*Q1 pad a block to 64
+        // reflectors and need the zeros of all 64 columns; with at most 16 reflectors J*Q1 runs reflector by reflector
+        // (k_jq1_rows*, k_jq1_factor_small: the diagonal; launch_jq1 of the accessors: the upper triangle of the first kA columns),
+        // so only those columns are written — 30 of the 32 KB per problem at C5 (t = 4) were zeros nobody reads: 250 MB per step
         double* T = a.TA + prob * a.sTA;
-        for (int jc = 0; jc < KBLK; ++jc) T[ln + jc * KBLK] = (jc < kA && ln <= jc) ? Tl[ln + 64 * jc] : 0.0;
+        const int jcols = (kA <= Q1R_MAXK) ? kA : KBLK;
+        for (int jc = 0; jc < jcols; ++jc) T[ln + jc * KBLK] = (jc < kA && ln <= jc) ? Tl[ln + 64 * jc] : 0.0;
     }
     const int rankA = wave_pseudo_rank(dg, kA, a.eps_rank, ln);
     int code = (rankA == t) ? 1 : -1;
