@@ -201,16 +201,27 @@ __device__ __forceinline__ ArgMax half_argmax(double val, int pos, int idx, int 
     am_step<0x4E>(a);
     am_step<0x141>(a);
     am_step<0x140>(a);
-    ArgMax r[2];
+    // field by field, in named scalars: a per-lane choice between two STRUCTS is compiled as an indexed private array, i.e.
+    // scratch stores + a scratch load per step, and a scratch load's wait (vmcnt(0)) also waits for the acknowledgement of the
+    // step's global stores (tau, the Householder vector): ~1 us of HBM write latency on the critical path of every pivot step
+    double rv[2];
+    int rp[2], ri[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        r[h] = {readlane_f64(a.val, 32 * h), __builtin_amdgcn_readlane(a.pos, 32 * h), __builtin_amdgcn_readlane(a.idx, 32 * h)};
+        rv[h] = readlane_f64(a.val, 32 * h);
+        rp[h] = __builtin_amdgcn_readlane(a.pos, 32 * h);
+        ri[h] = __builtin_amdgcn_readlane(a.idx, 32 * h);
         const double ov = readlane_f64(a.val, 32 * h + 16);
         const int op = __builtin_amdgcn_readlane(a.pos, 32 * h + 16);
         const int oi = __builtin_amdgcn_readlane(a.idx, 32 * h + 16);
-        if (am_better(ov, op, r[h].val, r[h].pos)) r[h] = {ov, op, oi};
+        if (am_better(ov, op, rv[h], rp[h])) { rv[h] = ov; rp[h] = op; ri[h] = oi; }
     }
-    return (ln & 32) ? r[1] : r[0];
+    const bool up = (ln & 32) != 0;
+    ArgMax r;
+    r.val = up ? rv[1] : rv[0];
+    r.pos = up ? rp[1] : rp[0];
+    r.idx = up ? ri[1] : ri[0];
+    return r;
 }
 // x of lane srcA (lower half) / srcB (upper half), both wave-uniform, in every lane of the respective half
 __device__ __forceinline__ double half_bcast(double x, int srcA, int srcB, int ln) {
