@@ -99,6 +99,19 @@ __device__ __forceinline__ long long caqr_block_row(const CaqrArgs& a, long long
 #ifndef ENLSIP_FACTOR_OCC16
 #define ENLSIP_FACTOR_OCC16 8
 #endif
+// timing experiments only (tests/microbench/factor_bench.hip; results wrong when != 0): 1 no reflector arithmetic (norm reduction,
+// dlarfg), 2 no reduction of the dot products, 3 no T factor, 4 no barrier inside the step loop, 5 no step loop, 6 no dot products /
+// column updates
+#ifndef ENLSIP_FACTOR_ABLATE
+#define ENLSIP_FACTOR_ABLATE 0
+#endif
+constexpr int FACTOR_ABLATE = ENLSIP_FACTOR_ABLATE;
+#ifdef ENLSIP_FACTOR_STAMPS     // harness only: phase stamps (100 MHz) of one workgroup
+__device__ long long g_factor_stamps[16];
+#define FACTOR_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 3 && blockIdx.y == 7 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_factor_stamps[i] = wall_clock64(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FACTOR_STAMP(i) do { } while (0)
+#endif
 // The factorisation of one group with the tile in registers.  PRE = true: x already holds the tile (the fused small-problem
 // kernel gn_kernels_small_fused.hpp hands it over without the round trip through HBM).
 template <int RPL, int NW, bool PRE>
@@ -117,6 +130,7 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
     double* W = a.W + prob * a.sW;
     const bool tri = a.level > 0;
 
+    FACTOR_STAMP(0);
     for (int e = threadIdx.x; e < PB * (PB + 1); e += NT) (&gsh[0][0])[e] = 0.0;
     if (threadIdx.x < PB) taush[threadIdx.x] = 0.0;
 
@@ -150,10 +164,11 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
         }
     }
     __syncthreads();
+    FACTOR_STAMP(1);
 
 #pragma unroll
     for (int jj = 0; jj < NC; ++jj) {
-        for (int jw = 0; jw < NW; ++jw) {
+        for (int jw = 0; jw < (FACTOR_ABLATE == 5 ? 0 : NW); ++jw) {
             int lnl = ln;                      // opaque per-iteration copy: keeps LICM from hoisting (and spilling) the row masks
             asm volatile("" : "+v"(lnl));
             const int j = NW * jj + jw;  // wave-uniform
@@ -167,9 +182,9 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
                     double xn2 = (lnl > dj) ? x[jj][0] * x[jj][0] : 0.0;
 #pragma unroll
                     for (int i = 1; i < RPL; ++i) xn2 += x[jj][i] * x[jj][i];
-                    xn2 = wave_allsum(xn2);
-                    const double alpha = wave_bcast(x[jj][0], dj);
-                    const Reflector h = make_reflector(alpha, xn2);
+                    if (FACTOR_ABLATE != 1) xn2 = wave_allsum(xn2);
+                    const double alpha = (FACTOR_ABLATE == 1) ? x[jj][0] : wave_bcast(x[jj][0], dj);
+                    const Reflector h = (FACTOR_ABLATE == 1) ? Reflector{0.5 * alpha, 1.5, 0.25 * xn2} : make_reflector(alpha, xn2);
                     {
                         const double v = (lnl > dj) ? x[jj][0] * h.scale : (lnl == dj ? 1.0 : 0.0);
                         vsh[buf][lnl] = v;
@@ -183,7 +198,7 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
                     }
                     if (lnl == 0) taush[j] = h.tau;
                 }
-                __syncthreads();
+                if (FACTOR_ABLATE != 4) __syncthreads();
                 double v[RPL];
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) v[i] = vsh[buf][lnl + 64 * i];
@@ -193,17 +208,20 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
                 for (int cc = 0; cc < NC; ++cc) {
                     dot[cc] = 0.0;
 #pragma unroll
-                    for (int i = 0; i < RPL; ++i) dot[cc] += x[cc][i] * v[i];
+                    for (int i = 0; i < (FACTOR_ABLATE == 6 ? 1 : RPL); ++i) dot[cc] += x[cc][i] * v[i];
                 }
                 double ds[NC];
-                wave_allsumN(dot, ds);     // NC reductions sharing one transposed butterfly
+                if (FACTOR_ABLATE == 2) {
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) ds[cc] = dot[cc];
+                } else wave_allsumN(dot, ds);     // NC reductions sharing one transposed butterfly
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) {
                     const int c = w + NW * cc;
                     if (c > j) {
                         const double wd = tj * ds[cc];
 #pragma unroll
-                        for (int i = 0; i < RPL; ++i) x[cc][i] -= wd * v[i];
+                        for (int i = 0; i < (FACTOR_ABLATE == 6 ? 1 : RPL); ++i) x[cc][i] -= wd * v[i];
                     } else if (c < j) {
                         // Gram entry v_c' v_j for the T factor: rows above slot j are masked by
                         // v (zero there), so the R entries held in x[cc] do not contribute
@@ -214,6 +232,7 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
         }
     }
     __syncthreads();
+    FACTOR_STAMP(2);
     // store the tile back (V below / R on and above the diagonal; tree levels: upper triangles)
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
@@ -224,8 +243,9 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
             if (ok) W[ubase(c, i) + lane_off] = x[cc][i];
         }
     }
+    FACTOR_STAMP(3);
     // T factor (dlarft forward/columnwise): lane r of wave 0 builds row r
-    if (w == 0) {
+    if (w == 0 && FACTOR_ABLATE != 3) {
         double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
         if (ln < PB) {
             // row ln of T in registers, loops fully unrolled and branch-free: T is upper triangular, so trow[l] = 0
@@ -244,6 +264,7 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
             }
         }
     }
+    FACTOR_STAMP(4);
 }
 
 template <int RPL, int NW>
