@@ -244,24 +244,30 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
         }
     }
     FACTOR_STAMP(3);
-    // T factor (dlarft forward/columnwise): lane r of wave 0 builds row r
+    // T factor (dlarft forward/columnwise) by wave 0: lanes r and r + 32 build row r, each holding every second entry of it
     if (w == 0 && FACTOR_ABLATE != 3) {
         double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
-        if (ln < PB) {
-            // row ln of T in registers, loops fully unrolled and branch-free: T is upper triangular, so trow[l] = 0
-            // for l < ln and the plain sum over l < j is the dlarft sum over ln <= l < j; gsh / taush are zero where no
-            // reflector exists.  (The tile registers are dead here.  A lane-bounded loop over LDS rows cost ~20 us.)
-            double trow[PB];
+        // Row r of T in registers, loops fully unrolled and branch-free: T is upper triangular, so trow[l] = 0 for l < r and the
+        // plain sum over l < j is the dlarft sum over r <= l < j; gsh / taush are zero where no reflector exists.  (A lane-bounded
+        // loop over LDS rows cost ~20 us.)  The row is split over the two half-waves — half hh holds trh[i] = T[r][2 i + hh] and
+        // sums its own l, one cross-half add per column: with the whole row in one lane (64 registers) and the Gram column reads
+        // hoisted above it the epilogue spilled, and a scratch reload waits (vmcnt(0)) for the acknowledgement of the tile's stores
+        // issued just before — seven HBM write round trips inside a 7 us epilogue that the other seven waves of the workgroup sit
+        // out.
+        const int r = ln & 31, hh = ln >> 5;
+        double trh[PB / 2];
 #pragma unroll
-            for (int j = 0; j < PB; ++j) {
-                const double tj = taush[j];
-                double s = 0.0;
+        for (int i = 0; i < PB / 2; ++i) trh[i] = 0.0;
 #pragma unroll
-                for (int l = 0; l < j; ++l) s += trow[l] * gsh[l][j];
-                const double tv = (ln == j) ? tj : ((ln < j) ? -tj * s : 0.0);
-                trow[j] = tv;
-                T[ln + j * PB] = tv;
-            }
+        for (int j = 0; j < PB; ++j) {
+            const double tj = taush[j];
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; 2 * i < j; ++i) s += trh[i] * gsh[2 * i + hh][j];   // l = 2 i + hh <= j; the entry l = j is still zero
+            s = xor32_sum(s);
+            const double tv = (r == j) ? tj : ((r < j) ? -tj * s : 0.0);
+            trh[j >> 1] = ((j & 1) == hh) ? tv : trh[j >> 1];
+            if ((j & 1) == hh) T[r + j * PB] = tv;
         }
     }
     FACTOR_STAMP(4);
