@@ -126,6 +126,54 @@ __device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrc
     }
 }
 
+// The step loop on NRX register rows from row offset j0 on: blocks of WQ_UNROLL steps, the rows shifted up after each, until
+// no step is left or — rem_stop > 0 — the live rows (q.rows - j0) fit rem_stop registers.  Returns true when steps remain
+// (the rows have been shifted; x[r] is row j0 + r).
+template <int NRX, bool GRAM>
+__device__ __forceinline__ bool wave_qrcp_blocks(double (&x)[NRX], const WaveQrcp& q, const int ln, int& mypos, double& vn1, double& vn2,
+                                                 double& myscale, int& j0, const int rem_stop) {
+    // single exit at the bottom (the shift of the last block is skipped, not jumped over): with a `break` in the middle the
+    // compiler carries the exit copy and the next-iteration copy of the register rows through the loop (two register sets and
+    // a full copy per block; see k_sb_factor_reg)
+    bool more, go;
+    do {
+        const int rem = q.rows - j0;
+#define GN_WQ_STEP(S) \
+    if (j0 + S < q.k) wave_qrcp_substep<NRX, S, GRAM>(x, q, j0 + S, rem, ln, mypos, vn1, vn2, myscale);
+        GN_WQ_STEP(0) GN_WQ_STEP(1) GN_WQ_STEP(2) GN_WQ_STEP(3)
+#undef GN_WQ_STEP
+        more = j0 + WQ_UNROLL < q.k;
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < NRX; ++r) x[r] = (r + WQ_UNROLL < NRX) ? x[(r + WQ_UNROLL < NRX) ? r + WQ_UNROLL : r] : 0.0;
+            j0 += WQ_UNROLL;
+        }
+        go = more && (q.rows - j0 > rem_stop);
+    } while (go);
+    return more;
+}
+// register rows of the next, smaller instance of the step loop (0: none)
+constexpr int wq_next_rows(int nr) { return nr > 32 ? nr - 16 : (nr > 8 ? nr - 8 : 0); }
+// ... and the rest of the factorisation on FEWER register rows once the live rows fit them (a step costs its instructions —
+// one publish, one read-back, two FMAs per register row whether the row is live or not — and the later steps of a
+// factorisation have few live rows).  Rows beyond the live range are zero, so the arithmetic is the same to the last bit.
+template <int NRX, bool GRAM>
+__device__ __forceinline__ void wave_qrcp_run(double (&x)[NRX], const WaveQrcp& q, const int ln, int& mypos, double& vn1, double& vn2,
+                                              double& myscale, int& j0) {
+    constexpr int NXT = wq_next_rows(NRX);
+    const bool more = wave_qrcp_blocks<NRX, GRAM>(x, q, ln, mypos, vn1, vn2, myscale, j0, NXT);
+    if constexpr (NXT > 0) {
+        if (more) {
+            double y[NXT];
+#pragma unroll
+            for (int r = 0; r < NXT; ++r) y[r] = x[r];
+            wave_qrcp_run<NXT, GRAM>(y, q, ln, mypos, vn1, vn2, myscale, j0);
+#pragma unroll
+            for (int r = 0; r < NRX; ++r) x[r] = (r < NXT) ? y[(r < NXT) ? r : 0] : 0.0;
+        }
+    }
+}
+
 // Factorisation driver.  x: the lane's column (rows 0..NR-1, zero beyond q.rows and in idle lanes).  On return mypos is
 // the LAPACK position of the lane's column and the register rows are relative to the returned row offset j0 (the last
 // block is not shifted out, so rows >= k of a carried right-hand side are still in x[row - j0]).
@@ -146,23 +194,7 @@ __device__ __forceinline__ int wave_qrcp(double (&x)[NR], const WaveQrcp& q, con
     double vn2 = vn1, myscale = 0.0;
     mypos = ln;
     int j0 = 0;
-    // single exit at the bottom (the shift of the last block is skipped, not jumped over): with a `break` in the middle the
-    // compiler carries the exit copy and the next-iteration copy of the register rows through the loop (two register sets and
-    // a full copy per block; see k_sb_factor_reg)
-    bool more;
-    do {
-        const int rem = q.rows - j0;
-#define GN_WQ_STEP(S) \
-    if (j0 + S < q.k) wave_qrcp_substep<NR, S, GRAM>(x, q, j0 + S, rem, ln, mypos, vn1, vn2, myscale);
-        GN_WQ_STEP(0) GN_WQ_STEP(1) GN_WQ_STEP(2) GN_WQ_STEP(3)
-#undef GN_WQ_STEP
-        more = j0 + WQ_UNROLL < q.k;
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = (r + WQ_UNROLL < NR) ? x[(r + WQ_UNROLL < NR) ? r + WQ_UNROLL : r] : 0.0;
-            j0 += WQ_UNROLL;
-        }
-    } while (more);
+    wave_qrcp_run<NR, GRAM>(x, q, ln, mypos, vn1, vn2, myscale, j0);
     return j0;
 }
 
@@ -315,6 +347,43 @@ __device__ __forceinline__ void wave_qrcp2_substep(double (&x)[NR], const WaveQr
     }
 }
 
+// Step loop of the two-problem form on NRX register rows (see wave_qrcp_blocks); rows_max = the larger row count of the two problems.
+template <int NRX>
+__device__ __forceinline__ bool wave_qrcp2_blocks(double (&x)[NRX], const WaveQrcp2& q, const int kmax, const int rows_max, const int ln,
+                                                  int& mypos, double& vn1, double& vn2, int& j0, const int rem_stop) {
+    bool more, go;                // single exit at the bottom, as in wave_qrcp_blocks
+    do {
+#define GN_WQ2_STEP(S) \
+    if (j0 + S < kmax) wave_qrcp2_substep<NRX, S>(x, q, j0 + S, ln, mypos, vn1, vn2);
+        GN_WQ2_STEP(0) GN_WQ2_STEP(1) GN_WQ2_STEP(2) GN_WQ2_STEP(3)
+#undef GN_WQ2_STEP
+        more = j0 + WQ_UNROLL < kmax;
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < NRX; ++r) x[r] = (r + WQ_UNROLL < NRX) ? x[(r + WQ_UNROLL < NRX) ? r + WQ_UNROLL : r] : 0.0;
+            j0 += WQ_UNROLL;
+        }
+        go = more && (rows_max - j0 > rem_stop);
+    } while (go);
+    return more;
+}
+template <int NRX>
+__device__ __forceinline__ void wave_qrcp2_run(double (&x)[NRX], const WaveQrcp2& q, const int kmax, const int rows_max, const int ln,
+                                               int& mypos, double& vn1, double& vn2, int& j0) {
+    constexpr int NXT = wq_next_rows(NRX);
+    const bool more = wave_qrcp2_blocks<NRX>(x, q, kmax, rows_max, ln, mypos, vn1, vn2, j0, NXT);
+    if constexpr (NXT > 0) {
+        if (more) {
+            double y[NXT];
+#pragma unroll
+            for (int r = 0; r < NXT; ++r) y[r] = x[r];
+            wave_qrcp2_run<NXT>(y, q, kmax, rows_max, ln, mypos, vn1, vn2, j0);
+#pragma unroll
+            for (int r = 0; r < NRX; ++r) x[r] = (r < NXT) ? y[(r < NXT) ? r : 0] : 0.0;
+        }
+    }
+}
+
 // Driver of the two-problem form; kmax = the larger step count of the two problems (wave-uniform).  Returns the row offset of the
 // registers (as wave_qrcp).
 template <int NR>
@@ -334,19 +403,8 @@ __device__ __forceinline__ int wave_qrcp2(double (&x)[NR], const WaveQrcp2& q, c
     double vn2 = vn1;
     mypos = ln & 31;
     int j0 = 0;
-    bool more;                // single exit at the bottom, as in wave_qrcp
-    do {
-#define GN_WQ2_STEP(S) \
-    if (j0 + S < kmax) wave_qrcp2_substep<NR, S>(x, q, j0 + S, ln, mypos, vn1, vn2);
-        GN_WQ2_STEP(0) GN_WQ2_STEP(1) GN_WQ2_STEP(2) GN_WQ2_STEP(3)
-#undef GN_WQ2_STEP
-        more = j0 + WQ_UNROLL < kmax;
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = (r + WQ_UNROLL < NR) ? x[(r + WQ_UNROLL < NR) ? r + WQ_UNROLL : r] : 0.0;
-            j0 += WQ_UNROLL;
-        }
-    } while (more);
+    const int ra = __builtin_amdgcn_readlane(q.rows, 0), rb = __builtin_amdgcn_readlane(q.rows, 32);
+    wave_qrcp2_run<NR>(x, q, kmax, ra > rb ? ra : rb, ln, mypos, vn1, vn2, j0);
     return j0;
 }
 
