@@ -114,7 +114,35 @@ __device__ long long g_factor_stamps[16];
 #endif
 // The factorisation of one group with the tile in registers.  PRE = true: x already holds the tile (the fused small-problem
 // kernel gn_kernels_small_fused.hpp hands it over without the round trip through HBM).
-template <int RPL, int NW, bool PRE>
+// All-reduce of the LAST `live` entries of dot (the columns of a wave that are still being updated), smallest transposed butterfly
+// that holds them; the other entries of out are not written.
+template <int NC>
+__device__ __forceinline__ void wave_allsum_last(const double (&dot)[NC], double (&out)[NC], const int live) {
+    if (NC > 4 && live > 4) {
+        wave_allsumN(dot, out);
+    } else if (NC >= 4 && live > 2) {
+        double d4[4], o4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d4[i] = dot[NC - 4 + i];
+        wave_allsum4(d4, o4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[NC - 4 + i] = o4[i];
+    } else if (NC >= 2 && live > 1) {
+        double d2[2], o2[2];
+        d2[0] = dot[NC - 2]; d2[1] = dot[NC - 1];
+        wave_allsumN(d2, o2);
+        out[NC - 2] = o2[0]; out[NC - 1] = o2[1];
+    } else {
+        out[NC - 1] = wave_allsum(dot[NC - 1]);
+    }
+}
+
+// GRAM = false: the group's T factor is never read beyond its diagonal (a last, narrow panel whose only trailing column rides
+// through the factorisation as a passenger: no block update follows, and the reflector-by-reflector consumers read tau from
+// diag(T)).  The Gram entries v_c' v_j — the dot products of a step with the FINISHED columns — are then not needed: a step
+// forms dot products only for the columns it still updates (cc >= jj: columns w + NW cc with cc < jj are finished in every
+// wave), reduces them with the smallest butterfly that holds them, and the T epilogue writes diag(T) = tau.
+template <int RPL, int NW, bool PRE, bool GRAM = true>
 __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int prob, const ProbState& st, double (&x)[PB / NW][RPL],
                                                  double (*vsh)[64 * RPL], double* taush, double (*gsh)[PB + 1]) {   // 2nd bound = waves per SIMD
     constexpr int NC = PB / NW;
@@ -131,7 +159,8 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
     const bool tri = a.level > 0;
 
     FACTOR_STAMP(0);
-    for (int e = threadIdx.x; e < PB * (PB + 1); e += NT) (&gsh[0][0])[e] = 0.0;
+    if (GRAM)
+        for (int e = threadIdx.x; e < PB * (PB + 1); e += NT) (&gsh[0][0])[e] = 0.0;
     if (threadIdx.x < PB) taush[threadIdx.x] = 0.0;
 
     // slot geometry of this lane: slot ln + 64 i = block q = (ln >> 5) + 2 i of the group, row rb of that block.
@@ -203,26 +232,31 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) v[i] = vsh[buf][lnl + 64 * i];
                 const double tj = taush[j];
+                const int cc_lo = GRAM ? 0 : jj;          // first column slot that can still be live (a constant once jj is unrolled)
                 double dot[NC];
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) {
                     dot[cc] = 0.0;
+                    if (cc >= cc_lo) {
 #pragma unroll
-                    for (int i = 0; i < (FACTOR_ABLATE == 6 ? 1 : RPL); ++i) dot[cc] += x[cc][i] * v[i];
+                        for (int i = 0; i < (FACTOR_ABLATE == 6 ? 1 : RPL); ++i) dot[cc] += x[cc][i] * v[i];
+                    }
                 }
                 double ds[NC];
                 if (FACTOR_ABLATE == 2) {
 #pragma unroll
                     for (int cc = 0; cc < NC; ++cc) ds[cc] = dot[cc];
-                } else wave_allsumN(dot, ds);     // NC reductions sharing one transposed butterfly
+                } else if (GRAM) wave_allsumN(dot, ds);     // NC reductions sharing one transposed butterfly
+                else wave_allsum_last<NC>(dot, ds, NC - jj);
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) {
+                    if (cc < cc_lo) continue;
                     const int c = w + NW * cc;
                     if (c > j) {
                         const double wd = tj * ds[cc];
 #pragma unroll
                         for (int i = 0; i < (FACTOR_ABLATE == 6 ? 1 : RPL); ++i) x[cc][i] -= wd * v[i];
-                    } else if (c < j) {
+                    } else if (GRAM && c < j) {
                         // Gram entry v_c' v_j for the T factor: rows above slot j are masked by
                         // v (zero there), so the R entries held in x[cc] do not contribute
                         if (lnl == 0) gsh[c][j] = ds[cc];
@@ -245,7 +279,18 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
     }
     FACTOR_STAMP(3);
     // T factor (dlarft forward/columnwise) by wave 0: lanes r and r + 32 build row r, each holding every second entry of it
-    if (w == 0 && FACTOR_ABLATE != 3) {
+    if (!GRAM) {
+        if (w == 0) {                // diag(T) = tau, zeros elsewhere (lane r + 32 hh writes every second entry of row r)
+            double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
+            const int r = ln & 31, hh = ln >> 5;
+            const double tr = taush[r];
+#pragma unroll
+            for (int j2 = 0; j2 < PB / 2; ++j2) {
+                const int j = 2 * j2 + hh;
+                T[r + j * PB] = (r == j) ? tr : 0.0;
+            }
+        }
+    } else if (w == 0 && FACTOR_ABLATE != 3) {
         double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
         // Row r of T in registers, loops fully unrolled and branch-free: T is upper triangular, so trow[l] = 0 for l < r and the
         // plain sum over l < j is the dlarft sum over r <= l < j; gsh / taush are zero where no reflector exists.  (A lane-bounded
@@ -281,7 +326,10 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? ENLSIP_FACTOR_OCC16 : (NW == 8 
     const int prob = blockIdx.y + a.prob0;
     const ProbState st = a.state[prob];
     double x[PB / NW][RPL];
-    caqr_factor_core<RPL, NW, false>(a, prob, st, x, vsh, taush, gsh);
+    // a passenger launch factors last panels narrower than 32 whose only trailing column rides along: no T beyond its diagonal
+    const int left = st.kp - a.panel * PB;
+    if (a.npass && left < PB) caqr_factor_core<RPL, NW, false, false>(a, prob, st, x, vsh, taush, gsh);
+    else caqr_factor_core<RPL, NW, false, true>(a, prob, st, x, vsh, taush, gsh);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256, 4) void k_jq1_factor_small(JQ1Args q, CaqrArgs
         __syncthreads();
     }
     // ---- the panel factorisation with the tile already in registers; V, R and T go where the other kernels expect them -------
-    caqr_factor_core<RPL, NW, true>(a, prob, st, x, vsh, taush, gsh);
+    // (always a passenger launch on a panel narrower than 32: the T factor is never read beyond its diagonal)
+    caqr_factor_core<RPL, NW, true, false>(a, prob, st, x, vsh, taush, gsh);
 }
 
 // true when the fused kernel serves the launch shape (one 256-row tile, one panel narrower than 32 with d as passenger)
