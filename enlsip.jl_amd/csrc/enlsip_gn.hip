@@ -654,9 +654,15 @@ static int run_qrcp_dist(enlsip_gn_handle h, int n2_launch) {
 }
 
 // blocked pivoted QR of R0 with verified pivots (gn_kernels_qrcp_block.hpp)
+// More than 512 rows do not fit the register forms: the stage then opens with a launch-per-step HEAD (k_qd_step, 8.4 us per step)
+// until 512 rows are left and hands the rest to the blocks (~3 us per step + ~50 us per block).  The two forms share their state
+// (M, norms, maps, reflectors by position); the head ends on an even step so that the maps sit in parity 0, where the blocks keep
+// them.  C4's 1024 x 1024 combine: 1024 head steps = 8.6 ms -> 512 head steps + 16 blocks.
 static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     const Plan& P = h->plan;
     const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
+    int jhead = kp_launch > 512 ? kp_launch - 512 : 0;
+    jhead += jhead & 1;
     SbArgs a{};
     QdArgs& q = a.q;
     q.n = (int)P.n; q.ldw = P.ldw; q.ldr = P.ldr; q.step = -1; q.prob0 = 0;
@@ -689,23 +695,32 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     bool hints = h->sb_form_hints && h->sb_rows_kp == kp_launch && h->sb_rows_batch == P.batch && !h->sb_rows_max.empty();
     const bool hinted = hints;
     bool fell_back = false;
-    hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, s, q);
-    hipLaunchKernelGGL(k_sb_reset, dim3(((unsigned)P.n + 255) / 256, (unsigned)P.batch), dim3(256), 0, s, a, (int)P.n);
+    if (jhead > 0) {
+        hipLaunchKernelGGL(k_qd_init<16>, grid, dim3(256), 0, s, q);
+        for (int j = 0; j < jhead; ++j) {
+            q.step = j;
+            hipLaunchKernelGGL(k_qd_step<16>, grid, dim3(256), 0, s, q);
+        }
+        q.step = -1;
+        q.hyb = jhead;
+    } else hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL(k_sb_reset, dim3(((unsigned)P.n + 255) / 256, (unsigned)P.batch), dim3(256), 0, s, a, (int)P.n, jhead);
+    const int kp_blk = kp_launch - jhead;           // steps (= rows) left to the blocks
     dim3 ugrid((n2_launch + 1 + SB_UCW - 1) / SB_UCW, (unsigned)P.batch);
     int it = 0;
     // blocks of <= 32 steps; the first chunk is sized from the previous solve on this handle (one host check per
     // solve in steady state), later chunks are small
-    int chunk = std::min(kp_launch, h->sb_hint > 0 ? h->sb_hint : kp_launch / 16 + 4);
+    int chunk = std::min(kp_blk, h->sb_hint > 0 ? h->sb_hint : kp_blk / 16 + 4);
     SbInfo* hinfo = (SbInfo*)h->h_sbinfo;
-    while (it < kp_launch) {
-        for (int i = 0; i < chunk && it < kp_launch; ++i, ++it) {
+    while (it < kp_blk) {
+        for (int i = 0; i < chunk && it < kp_blk; ++i, ++it) {
             a.blkid = it;
             GN_TRACE(h, "  qrcp block %d", it);
             // candidates in the registers of one workgroup (kp <= 512), block reflector applied to the still-active columns.
             // Up to three forms per block, each problem runs in the one that fits its current row count kp - j0
             // (gn_kernels_qrcp_block_reg.hpp); after `it` blocks every problem has made at least `it` steps, so the large
             // forms are no longer launched once kp_launch - it fits a smaller one.
-            const int rows_max = kp_launch - it;
+            const int rows_max = kp_blk - it;
             const dim3 fg((unsigned)P.batch);
             bool big = rows_max > 256, med = rows_max > 128, small = true;
             if (hints && it < (int)h->sb_rows_max.size() && h->sb_rows_max[it] > 0) {
@@ -716,7 +731,7 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
                 small = lo <= 128;
             }
             if (big) {
-                if (kp_launch <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8, 4>), fg, dim3(512), 0, s, a);
+                if (kp_blk <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8, 4>), fg, dim3(512), 0, s, a);
                 else hipLaunchKernelGGL((k_sb_factor_reg<8, 8, 4>), fg, dim3(512), 0, s, a);
             }
             if (med) hipLaunchKernelGGL((k_sb_factor_reg<4, 8, 2>), fg, dim3(512), 0, s, a);
@@ -980,7 +995,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
             if ((size_t)kp_launch * (n2_launch + 1) > (size_t)CMAT_DOUBLES) {
                 // more than 512 rows do not fit the register form of the blocked factorisation: one launch per pivot step
                 // (6.5 us per step; an LDS-slab blocked form was measured at 14 us per step and is gone)
-                rc = (kp_launch > 512) ? run_qrcp_dist(h, n2_launch) : run_qrcp_block(h, n2_launch);
+                rc = (kp_launch > 512 && !h->qrcp_hybrid) ? run_qrcp_dist(h, n2_launch) : run_qrcp_block(h, n2_launch);
                 if (rc) return rc;
                 fa.refactor = 2;
             }
@@ -1103,6 +1118,8 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         if (fs && fs[0] == '0') h->fuse_small = false;
         const char* fh = getenv("ENLSIP_GN_SB_FORM_HINTS");   // 0: every block of the blocked pivoted QR in all of its forms (A/B)
         if (fh && fh[0] == '0') h->sb_form_hints = false;
+        const char* hy = getenv("ENLSIP_GN_QRCP_HYBRID");     // 0: more than 512 rows = one launch per pivot step to the end (A/B)
+        if (hy && hy[0] == '0') h->qrcp_hybrid = false;
         const char* f4 = getenv("ENLSIP_GN_FACTOR_NW4");
         if (f4) h->factor_nw4 = atoi(f4);
         const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");

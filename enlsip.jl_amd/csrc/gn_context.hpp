@@ -86,6 +86,7 @@ struct enlsip_gn_context {
     gn::DevBuf sb_stat;          // device statistics (2 x SB_STAT_BLKS ints)
     int* h_sb_stat = nullptr;    // pinned mirror
     bool sb_form_hints = true;   // ENLSIP_GN_SB_FORM_HINTS=0: every block id in all three forms (A/B)
+    bool qrcp_hybrid = true;     // pivoted QR of more than 512 rows: launch-per-step head, register blocks for the last 512 (ENLSIP_GN_QRCP_HYBRID=0: A/B)
     int sb_hint = 0;             // blocks the previous blocked QRCP needed (+1): size of the first launch chunk
     double* sbT = nullptr;       // per problem: T factor of the current QRCP block (32 x 32)
     void* sbInfo = nullptr;      // SbInfo per problem (device)

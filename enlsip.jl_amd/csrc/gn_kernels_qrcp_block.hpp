@@ -59,12 +59,14 @@ constexpr int SB_STAT_BLKS = 1024;     // block ids (a block makes at least one 
 constexpr int SB_STAT_OFF = 1 << 20;
 
 // reset of the per-problem block state; runs after k_qd_init
-__global__ void k_sb_reset(SbArgs a, int n) {
+// j_first: pivot steps already done by a launch-per-step head (hybrid stage; 0 otherwise)
+__global__ void k_sb_reset(SbArgs a, int n, int j_first) {
     const int prob = blockIdx.y + a.q.prob0;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n) a.inblk[prob * a.sIn + c] = -1;
     if (c == 0) {
-        SbInfo z = {0, 0, -1, 0};
+        const int kp = a.q.state[prob].kp;
+        SbInfo z = {j_first < kp ? j_first : kp, 0, -1, 0};
         a.info[prob] = z;
     }
 }

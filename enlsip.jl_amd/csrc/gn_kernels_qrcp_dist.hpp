@@ -52,6 +52,8 @@ struct QdArgs {
     const double* Ain; long long ldain, sAin;
     const double* rin; long long sRin;
     double* Lout;      long long sLout;
+    int hyb;           // k_qd_assemble after a hybrid stage (run_qrcp_block with a launch-per-step head of `hyb` steps, hyb even): a
+                       // problem that finished inside the head keeps its maps in the parity of its step count, the others in 0
 };
 
 __device__ __forceinline__ int qd_rows(const QdArgs& a, int kp) { return a.rows > 0 ? a.rows : kp; }
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void k_qd_assemble(QdArgs a) {
     const int nst = qd_steps(a, st.kp, n2);
     const int g = blockIdx.x;
     if (kp == 0 || g * QD_CPW >= ctot) return;
-    const int par = (a.step < 0) ? 0 : (nst & 1);   // block form keeps a single (parity 0) map
+    const int par = (a.step < 0) ? ((a.hyb > 0 && nst <= a.hyb) ? (nst & 1) : 0) : (nst & 1);   // block form keeps a single (parity 0) map
     const int* colat = a.colat + prob * 2 * a.sI + par * a.sI;
     const double* M = a.M + prob * a.sM;
     const double* Vb = a.Vb + prob * a.sVb;

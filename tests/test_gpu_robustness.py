@@ -319,6 +319,33 @@ def test_blocked_qrcp_form_hints_never_change_a_result():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,n,t", [(900, 640, 20), (1100, 1024, 0), (700, 600, 88)])
+def test_hybrid_pivoted_qr_matches_the_launch_per_step_form(m, n, t):
+    """More than 512 rows of R0: the stage opens with one launch per pivot step and hands the last 512 rows to the register
+    blocks (run_qrcp_block, jhead); ENLSIP_GN_QRCP_HYBRID=0 keeps one launch per step to the end.  Same pivots, ranks and exit
+    codes in both forms and in the oracle, on a random, a graded (norm recomputations, short blocks) and a rank-deficient J
+    (the stage meets zero columns); kp = 620 / 1024 / 512 (the last one: no head at all, the hand-over offset is zero)."""
+    from enlsip_gn import GNSolver
+    for i, gen in enumerate([synth.make_problem, synth.make_graded_J, synth.make_rank_deficient_J]):
+        J, rx, A, cx = gen(9100 + 7 * i + m, m, n, t)
+        ref = go.gn_subproblem(J, rx, A, cx)
+        outs = []
+        for hyb in (1, 0):
+            s = _solver_with_env(ENLSIP_GN_QRCP_HYBRID=hyb)
+            try:
+                outs.append(s.solve(J, rx, A, cx))
+            finally:
+                s.close()
+        a, b = outs
+        assert (a.rankA, a.rankJ2, a.code) == (b.rankA, b.rankJ2, b.code) == (ref.rankA, ref.rankJ2, ref.code), (i, m, n, t)
+        r = ref.rankJ2
+        assert np.array_equal(a.jpvtJ2[:r], ref.jpvtJ2[:r]) and np.array_equal(b.jpvtJ2[:r], ref.jpvtJ2[:r]), (i, m, n, t)
+        tol = 1e-9 if gen is synth.make_problem else 1e-5
+        assert rel(a.p, ref.p) <= tol and rel(b.p, ref.p) <= tol, (i, rel(a.p, ref.p), rel(b.p, ref.p))
+        assert rel(a.p, b.p) <= tol
+
+
+@pytest.mark.gpu
 def test_fused_small_kernel_matches_the_two_launch_form():
     """One-tile problems with one narrow panel (C5's shape and neighbours): J*Q1 + panel in one launch (default) and as two launches
     (ENLSIP_GN_FUSE_SMALL=0) give the same factors, bit for bit — the fused kernel runs the same factorisation body on the same
