@@ -161,7 +161,9 @@ template <int NRX, bool GRAM>
 __device__ __forceinline__ void wave_qrcp_run(double (&x)[NRX], const WaveQrcp& q, const int ln, int& mypos, double& vn1, double& vn2,
                                               double& myscale, int& j0) {
     constexpr int NXT = wq_next_rows(NRX);
-    const bool more = wave_qrcp_blocks<NRX, GRAM>(x, q, ln, mypos, vn1, vn2, myscale, j0, NXT);
+    // (a matrix with few rows — F_L11 is t x rankA — starts on the smallest instance that holds it, not with a block on this one)
+    bool more = j0 < q.k;
+    if (NXT == 0 || q.rows - j0 > NXT) more = wave_qrcp_blocks<NRX, GRAM>(x, q, ln, mypos, vn1, vn2, myscale, j0, NXT);
     if constexpr (NXT > 0) {
         if (more) {
             double y[NXT];
@@ -371,7 +373,8 @@ template <int NRX>
 __device__ __forceinline__ void wave_qrcp2_run(double (&x)[NRX], const WaveQrcp2& q, const int kmax, const int rows_max, const int ln,
                                                int& mypos, double& vn1, double& vn2, int& j0) {
     constexpr int NXT = wq_next_rows(NRX);
-    const bool more = wave_qrcp2_blocks<NRX>(x, q, kmax, rows_max, ln, mypos, vn1, vn2, j0, NXT);
+    bool more = j0 < kmax;
+    if (NXT == 0 || rows_max - j0 > NXT) more = wave_qrcp2_blocks<NRX>(x, q, kmax, rows_max, ln, mypos, vn1, vn2, j0, NXT);
     if constexpr (NXT > 0) {
         if (more) {
             double y[NXT];
