@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/seq}; mkdir -p $O
 export ENLSIP_GN_PIPELINE=0
 for kv in "${@:2}"; do export "$kv"; done
-rocprofv3 --kernel-trace --output-format csv -d $O/ks -- python3 bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline --no-live-pmc > $O/bench.json 2> $O/ks.err
+rocprofv3 --kernel-trace --output-format csv -d $O/ks -- python3 bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline --no-live-pmc $SEQ_ARGS > $O/bench.json 2> $O/ks.err
 python3 - <<PY
 import csv, glob
 f = glob.glob("$O/ks/*/*kernel_trace.csv")[0]
