@@ -295,6 +295,43 @@ __device__ __forceinline__ Reflector make_reflector(double alpha, double xnorm2)
     return r;
 }
 
+// dlaqp2's downdate of a partial column norm o1 (o2 = the norm at its last recomputation) after a pivot step in which the column's
+// entry in the pivot row became ajc:  temp = max(0, 1 - (|ajc| / o1)^2), temp2 = temp (o1 / o2)^2;  temp2 <= tol3z: the norm has to be
+// recomputed (need), otherwise it becomes o1 sqrt(temp).  Caller guarantees o1 != 0.  Like make_reflector this sits on the dependent
+// chain of every pivot step (the next arg-max waits for it): reciprocals and the root by rcp / rsq with two Newton steps.
+struct NormDown {
+    double vn1;        // the downdated norm (meaningless when need)
+    bool need;
+};
+__device__ __forceinline__ NormDown norm_downdate(const double o1, const double o2, const double ajc, const double tol3z) {
+    NormDown r;
+#if ENLSIP_FAST_REFLECTOR
+    double r1 = __builtin_amdgcn_rcp(o1), r2 = __builtin_amdgcn_rcp(o2);
+    r1 = r1 * (2.0 - o1 * r1); r2 = r2 * (2.0 - o2 * r2);
+    r1 = r1 * (2.0 - o1 * r1); r2 = r2 * (2.0 - o2 * r2);
+    const double tq = fabs(ajc) * r1;
+    double temp = 1.0 - tq * tq;
+    temp = temp > 0.0 ? temp : 0.0;
+    const double qq = o1 * r2;
+    const double temp2 = temp * qq * qq;
+    r.need = temp2 <= tol3z;
+    double y = __builtin_amdgcn_rsq(temp);                   // temp == 0: need is set and the value below is not used
+    y = y * (1.5 - 0.5 * temp * y * y);
+    y = y * (1.5 - 0.5 * temp * y * y);
+    double sr = temp * y;
+    sr = sr + 0.5 * y * (temp - sr * sr);
+    r.vn1 = o1 * sr;
+#else
+    double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
+    temp = temp > 0.0 ? temp : 0.0;
+    const double qq = o1 / o2;
+    const double temp2 = temp * qq * qq;
+    r.need = temp2 <= tol3z;
+    r.vn1 = o1 * sqrt(temp);
+#endif
+    return r;
+}
+
 // pseudo_rank (src/enlsip_functions.jl:17-31), diag accessed through a functor; serial, call
 // from one lane.
 template <class DiagFn>

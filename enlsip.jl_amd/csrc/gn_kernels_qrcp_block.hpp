@@ -183,17 +183,14 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
     for (int t = 0; t < s; ++t) {
         if (o1 == 0.0) continue;
         const double ajc = col[t];
-        double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
-        temp = temp > 0.0 ? temp : 0.0;
-        const double qq = o1 / o2;
-        const double temp2 = temp * qq * qq;
-        if (temp2 <= tol3z) {
+        const NormDown nd = norm_downdate(o1, o2, ajc, tol3z);
+        if (nd.need) {
             double sq = srest;
             for (int t2 = s - 1; t2 > t; --t2) sq += col[t2] * col[t2];
             o1 = (jb + t + 1 < kp) ? sqrt(sq) : 0.0;
             o2 = o1;
         } else {
-            o1 = o1 * sqrt(temp);
+            o1 = nd.vn1;
         }
     }
     vn1[cc] = o1;

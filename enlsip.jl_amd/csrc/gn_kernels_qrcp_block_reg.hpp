@@ -405,12 +405,9 @@ __global__ __launch_bounds__(64 * NWV, RPL <= 2 ? 4 : (RPL <= 4 ? 3 : 2)) void k
             const double o2 = mine ? o2_in : 1.0;
             bool need = false;
             if (mine && o1 != 0.0) {
-                double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
-                temp = temp > 0.0 ? temp : 0.0;
-                const double qq = o1 / o2;
-                const double temp2 = temp * qq * qq;
-                if (temp2 <= tol3z) need = true;
-                else o1 = o1 * sqrt(temp);
+                const NormDown nd = norm_downdate(o1, o2, ajc, tol3z);
+                if (nd.need) need = true;
+                else o1 = nd.vn1;
             }
             unsigned nm = (unsigned)(__ballot(need) & ((1ull << NCW) - 1ull));
             while (nm) {                                   // rare: recompute the partial norm from the column

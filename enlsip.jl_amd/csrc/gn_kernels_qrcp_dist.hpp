@@ -268,11 +268,8 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
                     double o1 = cv1[u];
                     const double o2 = cv2[u];
                     if (o1 != 0.0) {
-                        double temp = 1.0 - (fabs(ajc) / o1) * (fabs(ajc) / o1);
-                        temp = temp > 0.0 ? temp : 0.0;
-                        const double qq = o1 / o2;
-                        const double temp2 = temp * qq * qq;
-                        if (temp2 <= tol3z) {
+                        const NormDown nd = norm_downdate(o1, o2, ajc, tol3z);
+                        if (nd.need) {
                             double s = 0.0;
 #pragma unroll
                             for (int i = 0; i < RPL; ++i)
@@ -284,7 +281,7 @@ __global__ __launch_bounds__(256) void k_qd_step(QdArgs a) {
                                 vn2[c] = o1;
                             }
                         } else {
-                            o1 = o1 * sqrt(temp);
+                            o1 = nd.vn1;
                             if (ln == 0) vn1[c] = o1;
                         }
                     }

@@ -109,11 +109,8 @@ __device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrc
     // (f) dlaqp2 norm downdate, lane-local
     if (upd && ln < q.ncand && vn1 != 0.0) {
         const double ajc = x[S];
-        double temp = 1.0 - (fabs(ajc) / vn1) * (fabs(ajc) / vn1);
-        temp = temp > 0.0 ? temp : 0.0;
-        const double qq = vn1 / vn2;
-        const double temp2 = temp * qq * qq;
-        if (temp2 <= tol3z) {
+        const NormDown nd = norm_downdate(vn1, vn2, ajc, tol3z);
+        if (nd.need) {
             double s2 = 0.0;
 #pragma unroll
             for (int r = S + 1; r < NR; ++r) s2 += x[r] * x[r];
@@ -121,7 +118,7 @@ __device__ __forceinline__ void wave_qrcp_substep(double (&x)[NR], const WaveQrc
             vn1 = nv;
             vn2 = nv;
         } else {
-            vn1 *= sqrt(temp);
+            vn1 = nd.vn1;
         }
     }
 }
@@ -332,11 +329,8 @@ __device__ __forceinline__ void wave_qrcp2_substep(double (&x)[NR], const WaveQr
     wave_mem_sync();          // every reader of vb is done before the next publish
     if (upd && lh < q.ncand && vn1 != 0.0) {
         const double ajc = x[S];
-        double temp = 1.0 - (fabs(ajc) / vn1) * (fabs(ajc) / vn1);
-        temp = temp > 0.0 ? temp : 0.0;
-        const double qq = vn1 / vn2;
-        const double temp2 = temp * qq * qq;
-        if (temp2 <= tol3z) {
+        const NormDown nd = norm_downdate(vn1, vn2, ajc, tol3z);
+        if (nd.need) {
             double s2 = 0.0;
 #pragma unroll
             for (int r = S + 1; r < NR; ++r) s2 += x[r] * x[r];
@@ -344,7 +338,7 @@ __device__ __forceinline__ void wave_qrcp2_substep(double (&x)[NR], const WaveQr
             vn1 = nv;
             vn2 = nv;
         } else {
-            vn1 *= sqrt(temp);
+            vn1 = nd.vn1;
         }
     }
 }

@@ -160,12 +160,9 @@ __device__ void wg_geqp2(double* __restrict__ A, int ld, int rows, int cols, int
             if (ln < G && cl < cols) {
                 const double o1 = vn1[cl], o2 = vn2[cl];
                 if (o1 != 0.0) {
-                    double temp = 1.0 - (fabs(ajl) / o1) * (fabs(ajl) / o1);
-                    temp = temp > 0.0 ? temp : 0.0;
-                    const double q = o1 / o2;
-                    const double temp2 = temp * q * q;
-                    if (temp2 <= tol3z) need = true;
-                    else vn1[cl] = o1 * sqrt(temp);
+                    const NormDown nd = norm_downdate(o1, o2, ajl, tol3z);
+                    if (nd.need) need = true;
+                    else vn1[cl] = nd.vn1;
                 }
             }
             const unsigned long long redo = __ballot(need);
