@@ -210,7 +210,30 @@ __device__ __forceinline__ void am_step(ArgMax& a) {
         a.idx = oi;
     }
 }
+// max over the rows of 16 lanes by DPP, the four row maxima combined through scalar registers: the same value in every lane
+__device__ __forceinline__ double wave_allmax(double x) {
+    x = fmax(x, dpp_f64<0xB1>(x));
+    x = fmax(x, dpp_f64<0x4E>(x));
+    x = fmax(x, dpp_f64<0x141>(x));
+    x = fmax(x, dpp_f64<0x140>(x));
+    return fmax(fmax(readlane_f64(x, 0), readlane_f64(x, 16)), fmax(readlane_f64(x, 32), readlane_f64(x, 48)));
+}
+// The exact (value, position) tournament below costs ~80 dependent operations and stands between the norm downdates of a pivot
+// step and the reflector of the next.  Almost always ONE lane holds the largest value: then a plain max tournament (3 operations
+// per level) and a ballot name the winner; an exact tie (or no candidate at all) takes the full tournament, so the result is
+// the same in every case.
+__device__ __forceinline__ ArgMax wave_argmax_exact(double val, int pos, int idx);
 __device__ __forceinline__ ArgMax wave_argmax(double val, int pos, int idx) {
+    const double m = wave_allmax(val);
+    const unsigned long long mk = __ballot(val == m);
+    if (__popcll(mk) == 1) {
+        const int l = (int)__builtin_ctzll(mk);
+        ArgMax r = {m, __builtin_amdgcn_readlane(pos, l), __builtin_amdgcn_readlane(idx, l)};
+        return r;
+    }
+    return wave_argmax_exact(val, pos, idx);
+}
+__device__ __forceinline__ ArgMax wave_argmax_exact(double val, int pos, int idx) {
     ArgMax a = {val, pos, idx};
     am_step<0xB1>(a);
     am_step<0x4E>(a);

@@ -226,7 +226,32 @@ __device__ __forceinline__ int wave_pseudo_rank(const double* dg, const int len,
 // 35 of its 64 lanes idle; the pivot stage is latency bound, so halving the number of waves nearly halves its time.
 // Everything wave-uniform in the one-problem form (pivot lane, reflector scalars, row counts) becomes uniform per HALF.
 // ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ ArgMax half_argmax_exact(double val, int pos, int idx, int ln);
+// as wave_argmax: a plain max tournament per half and a ballot when each half has ONE largest value, the exact tournament otherwise
 __device__ __forceinline__ ArgMax half_argmax(double val, int pos, int idx, int ln) {
+    double x = val;
+    x = fmax(x, dpp_f64<0xB1>(x));
+    x = fmax(x, dpp_f64<0x4E>(x));
+    x = fmax(x, dpp_f64<0x141>(x));
+    x = fmax(x, dpp_f64<0x140>(x));
+    const double mA = fmax(readlane_f64(x, 0), readlane_f64(x, 16)), mB = fmax(readlane_f64(x, 32), readlane_f64(x, 48));
+    const bool up = (ln & 32) != 0;
+    const double m = up ? mB : mA;
+    const unsigned long long mk = __ballot(val == m);
+    const unsigned lo = (unsigned)mk, hi = (unsigned)(mk >> 32);
+    if (__popc(lo) == 1 && __popc(hi) == 1) {
+        const int lA = __ffs((int)lo) - 1, lB = 32 + __ffs((int)hi) - 1;
+        ArgMax r;
+        r.val = m;
+        const int pA = __builtin_amdgcn_readlane(pos, lA), pB = __builtin_amdgcn_readlane(pos, lB);
+        const int iA = __builtin_amdgcn_readlane(idx, lA), iB = __builtin_amdgcn_readlane(idx, lB);
+        r.pos = up ? pB : pA;
+        r.idx = up ? iB : iA;
+        return r;
+    }
+    return half_argmax_exact(val, pos, idx, ln);
+}
+__device__ __forceinline__ ArgMax half_argmax_exact(double val, int pos, int idx, int ln) {
     ArgMax a = {val, pos, idx};
     am_step<0xB1>(a);
     am_step<0x4E>(a);
