@@ -179,21 +179,29 @@ __global__ __launch_bounds__(256, 2) void k_sb_update_blk(SbArgs a) {
     const double tol3z = 1.4901161193847656e-08;
     const double srest = (ssq[0][ln] + ssq[1][ln]) + (ssq[2][ln] + ssq[3][ln]);
     const double* col = stage[0] + ln * V4_LD + d;        // final entries of rows jb .. jb + 31 of this column
-    double o1 = vn1[cc], o2 = vn2[cc];
+    // The s downdates of a column in a row, on the SQUARED norm q = o1^2: dlaqp2's step
+    //     temp = max(0, 1 - (|a| / o1)^2), temp2 = temp (o1 / o2)^2, o1 <- o1 sqrt(temp)  unless temp2 <= tol3z (then recompute)
+    // is  q <- max(0, q - a^2)  unless  q - a^2 <= tol3z o2^2 : one multiply-add and a compare per step instead of two divisions and
+    // a square root, in a chain of up to 32 steps that one wave works off while the other three of the workgroup wait (4.7 us of a
+    // workgroup's 23); the norm itself is needed once, at the end.
+    const double o1_in = vn1[cc];
+    double q = o1_in * o1_in, o2 = vn2[cc], lim = tol3z * o2 * o2;
     for (int t = 0; t < s; ++t) {
-        if (o1 == 0.0) continue;
+        if (q == 0.0) continue;
         const double ajc = col[t];
-        const NormDown nd = norm_downdate(o1, o2, ajc, tol3z);
-        if (nd.need) {
+        double qn = q - ajc * ajc;
+        qn = qn > 0.0 ? qn : 0.0;
+        if (qn <= lim) {
             double sq = srest;
             for (int t2 = s - 1; t2 > t; --t2) sq += col[t2] * col[t2];
-            o1 = (jb + t + 1 < kp) ? sqrt(sq) : 0.0;
-            o2 = o1;
+            q = (jb + t + 1 < kp) ? sq : 0.0;
+            o2 = sqrt(q);
+            lim = tol3z * q;
         } else {
-            o1 = nd.vn1;
+            q = qn;
         }
     }
-    vn1[cc] = o1;
+    vn1[cc] = (q == o1_in * o1_in) ? o1_in : sqrt(q);      // untouched norms stay bit for bit
     vn2[cc] = o2;
 #ifdef ENLSIP_SB_STEP_STAMPS
     if (ub_st) atomicAdd((unsigned long long*)&g_sb_phase[11], (unsigned long long)(wall_clock64() - ub_t1));
