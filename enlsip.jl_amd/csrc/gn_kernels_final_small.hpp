@@ -53,19 +53,31 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : (
 
     GN_PS_STAMP(0);
     // ---- R0 (upper trapezoid) and z: columns through LDS so that the global loads run along rows ---------------
-    for (int c0 = 0; c0 <= n2; c0 += 8) {       // eight independent loads in flight, then eight LDS writes
-        double v[8];
+    // 32 independent loads in flight, then 32 LDS writes (the column registers are not live yet): with eight per round the 57
+    // columns of a C3 problem were eight HBM round trips in a row, 21 us of the kernel's 119
+    // The loads are UNCONDITIONAL (row and column clamped into the matrix) and masked with AND afterwards: a guarded load
+    // (`ok ? W[i] : 0`) is compiled as a branch around the load with a wait right behind it, so that the 57 columns of a C3 problem
+    // were 57 HBM round trips in a row.
+    constexpr int EXB = 32;
+    const int lnc = ln < kp ? ln : 0;
+    for (int c0 = 0; c0 <= n2; c0 += EXB) {
+        double v[EXB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < EXB; ++u) {
             const int c = c0 + u;
-            v[u] = 0.0;
-            if (ln < kp) {
-                if (c < n2) v[u] = (ln <= c) ? W[ln + (size_t)(rankA + c) * ldw] : 0.0;
-                else if (c == n2) v[u] = W[ln + (size_t)n * ldw];
-            }
+            const int col = (c < n2) ? rankA + c : n;          // uniform; columns past n2 read the carried right-hand side again
+            v[u] = W[lnc + (size_t)col * ldw];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < EXB; ++u) {
+            const int c = c0 + u;
+            const bool keep = (ln < kp) && ((c < n2) ? (ln <= c) : (c == n2));
+            const unsigned long long mk = keep ? ~0ull : 0ull;
+            v[u] = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v[u]) & mk));
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < EXB; ++u)
             if (ln < kp && c0 + u <= n2) tmp[ln * 65 + c0 + u] = v[u];
     }
     if (a.zsave && ln < kp) a.zsave[prob * a.sZ + ln] = W[ln + (size_t)n * ldw];
@@ -180,19 +192,26 @@ __global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) 
     const double* W = a.W + (size_t)prob_l * a.sW;
     double* Rt = a.Rt + (size_t)prob_l * a.sRt;
     // ---- R0 (upper trapezoid) and z: lane = row for the loads, columns through the LDS image ------------------------------
-    for (int c0 = 0; c0 < 32; c0 += 8) {
-        double v[8];
+    for (int c0 = 0; c0 < 32; c0 += 16) {        // 16 independent loads in flight (see k_pivot_small)
+        double v[16];
+        // unconditional loads from clamped addresses, masked with AND (see k_pivot_small)
+        const int lhc = (ok && lh < kp) ? lh : 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int c = c0 + u;
-            v[u] = 0.0;
-            if (ok && lh < kp) {
-                if (c < n2) v[u] = (lh <= c) ? W[lh + (size_t)(rankA + c) * ldw] : 0.0;
-                else if (c == n2) v[u] = W[lh + (size_t)n * ldw];
-            }
+            const int col = (c < n2) ? rankA + c : n;
+            v[u] = W[lhc + (size_t)col * ldw];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = c0 + u;
+            const bool keep = ok && (lh < kp) && ((c < n2) ? (lh <= c) : (c == n2));
+            const unsigned long long mk = keep ? ~0ull : 0ull;
+            v[u] = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v[u]) & mk));
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (lh < kpm) tmp[lh * 65 + hb + c0 + u] = v[u];
     }
     if (a.zsave && ok && lh < kp) a.zsave[(size_t)prob_l * a.sZ + lh] = W[lh + (size_t)n * ldw];

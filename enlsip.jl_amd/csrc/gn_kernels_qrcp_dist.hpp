@@ -84,7 +84,28 @@ __global__ __launch_bounds__(256) void k_qd_init(QdArgs a) {
         const int slot = 2 * w + u;
         const int c = g * QD_CPW + slot;
         double s = 0.0;
-        if (c < ctot) {
+        if (c < ctot && a.in_mode == 0) {
+            // R0 out of the CAQR storage: UNCONDITIONAL loads (row clamped into the matrix) masked with AND afterwards — a guarded
+            // load is compiled as a branch around the load with a wait right behind it, and the RPL loads of a column then are RPL
+            // HBM round trips in a row (the copy ran at half the stream rate)
+            const double* src = (c < n2) ? W + (size_t)(st.rankA + c) * a.ldw : W + (size_t)a.n * a.ldw;      // uniform
+            double v[RPL];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const int r = ln + 64 * i;
+                v[i] = src[r < kp ? r : 0];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const int r = ln + 64 * i;
+                const bool keep = (r < kp) && (c >= n2 || r <= c);
+                const unsigned long long mk = keep ? ~0ull : 0ull;
+                v[i] = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v[i]) & mk));
+                if (r < kp) M[r + (size_t)c * a.ldr] = v[i];
+                s += v[i] * v[i];
+            }
+        } else if (c < ctot) {
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 const int r = ln + 64 * i;
@@ -344,16 +365,26 @@ __global__ __launch_bounds__(256) void k_qd_assemble(QdArgs a) {
         const int k = g * QD_CPW + 2 * w + u;   // position
         if (k >= ctot) continue;
         const int c = (k < n2) ? colat[k] : n2;
-        for (int r = ln; r < kp; r += WAVE) {
-            double v;
-            if (k < nst) {
-                if (r < k) v = M[r + (size_t)c * a.ldr];
-                else if (r == k) v = a.diag[prob * a.sDiag + k];
-                else v = Vb[r + (size_t)k * a.ldr];
-            } else {
-                v = M[r + (size_t)c * a.ldr];
+        // eight rows per lane and round, every load unconditional from a per-lane choice of the source (R part of the column in M,
+        // reflector in Vb): with the choice as a branch around each load the copy paid one memory round trip per 64 rows
+        const double* mc = M + (size_t)c * a.ldr;
+        const double* vc = Vb + (size_t)k * a.ldr;
+        const double dk = (k < nst) ? a.diag[prob * a.sDiag + k] : 0.0;
+        for (int r0 = 0; r0 < kp; r0 += 8 * WAVE) {
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + ln + WAVE * i;
+                const int rc = r < kp ? r : 0;
+                const double* src = (k < nst && rc > k) ? vc + rc : mc + rc;
+                v[i] = *src;
             }
-            Rt[r + (size_t)k * a.ldr] = v;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + ln + WAVE * i;
+                if (r < kp) Rt[r + (size_t)k * a.ldr] = (k < nst && r == k) ? dk : v[i];
+            }
         }
         if (ln == 0 && k < n2) a.jpvt[prob * a.sJ + k] = c + 1;
     }
