@@ -41,22 +41,47 @@ __global__ __launch_bounds__(256, 4) void k_jq1_factor_small(JQ1Args q, CaqrArgs
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
 
     // ---- J Q1 and d_temp, a lane per row (k_jq1_rows) --------------------------------------------------------------------
-    // the row and its rx entry are requested FIRST: the staging of the reflectors (a global round trip and a barrier) then runs
-    // beside them instead of in front of them
+    // Order of the requests: the SMALL operands (reflectors of Q1, their tau, p1: a few values per thread) first, then the row of J
+    // and its rx entry, then the small operands go to LDS.  Loads retire in order under vmcnt, so a wait for a value requested
+    // AFTER the row also waits for the whole row; requested before it, the staging (a global round trip and a barrier) runs
+    // beside the row's 32 loads.  Every load is unconditional (row / column clamped into the matrix) and masked afterwards:
+    // guarded loads (`live && c < n ? J[..] : 0`) were partly compiled into branches with the wait right behind the load, and
+    // the row arrived in five memory round trips.
     const int row = tid;                                   // m <= 256: one workgroup holds every row
     const bool live = row < m;
-    double xr[NMAX];
+    static_assert(Q1R_MAXK * NMAX <= 2 * 256, "two staging entries per thread");
+    double fv[2];
+    bool fon[2], fone[2];
 #pragma unroll
-    for (int c = 0; c < NMAX; ++c) xr[c] = (live && c < n) ? __builtin_nontemporal_load(&Jin[row + (size_t)c * q.ldj]) : 0.0;
-    const double rxv = live ? rx[row] : 0.0;
-    for (int e = tid; e < kA * NMAX; e += 256) {
+    for (int h = 0; h < 2; ++h) {
+        const int e = tid + 256 * h;
         const int k = e / NMAX, c = e % NMAX;
-        double v = 0.0;
-        if (c < n) v = (c > k) ? FA[c + (size_t)k * n] : (c == k ? 1.0 : 0.0);
-        Vs[e] = v;
+        fon[h] = (e < kA * NMAX) && (c < n) && (c > k);
+        fone[h] = (e < kA * NMAX) && (c < n) && (c == k);
+        fv[h] = FA[fon[h] ? c + (size_t)k * n : 0];
     }
-    if (tid < kA) taus[tid] = TA[tid + tid * KBLK];       // dlarft: diag(T) = tau
-    if (tid < NMAX) p1s[tid] = (tid < rankA) ? p1[tid] : 0.0;
+    const double tauv = TA[(tid < kA ? tid : 0) * (KBLK + 1)];        // dlarft: diag(T) = tau
+    const double p1v = p1[tid < NMAX ? tid : 0];
+    __builtin_amdgcn_sched_barrier(0);                     // ... in THIS order
+    double xr[NMAX];
+    const int rowc = live ? row : 0;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) xr[c] = __builtin_nontemporal_load(&Jin[rowc + (size_t)(c < n ? c : 0) * q.ldj]);
+    double rxv = rx[rowc];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = tid + 256 * h;
+        if (e < kA * NMAX) Vs[e] = fon[h] ? fv[h] : (fone[h] ? 1.0 : 0.0);
+    }
+    if (tid < kA) taus[tid] = tauv;
+    if (tid < NMAX) p1s[tid] = (tid < rankA) ? p1v : 0.0;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+        const unsigned long long mk = (live && c < n) ? ~0ull : 0ull;
+        xr[c] = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(xr[c]) & mk));
+    }
+    rxv = live ? rxv : 0.0;
     __syncthreads();
     for (int k = 0; k < kA; ++k) {
         const double* vk = Vs + k * NMAX;
