@@ -301,8 +301,10 @@ __global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) 
                     v[i] = (act && r > j && r < n) ? FA[r + (size_t)j * n] : 0.0;
                 }
             };
-            const double tl = (act && lh < kA) ? tauA[lh] : 0.0;          // kA <= 32 reflectors here? no: up to 63 -> second word below
-            const double tl2 = (act && lh + 32 < kA) ? tauA[lh + 32] : 0.0;
+            // every tau in one request: lane lh of a half holds tau[lh + 32 q], q = 0..3 (kA <= n <= 128 on this path)
+            double tlq[RH];
+#pragma unroll
+            for (int qq = 0; qq < RH; ++qq) tlq[qq] = (act && lh + 32 * qq < kA) ? tauA[lh + 32 * qq] : 0.0;
             if (kA > 0) fetch(kA - 1, vn);
             for (int sidx = 0; sidx < kA; ++sidx) {
                 const int j = kA - 1 - sidx;
@@ -310,8 +312,11 @@ __global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) 
 #pragma unroll
                 for (int i = 0; i < RH; ++i) v[i] = (lh + 32 * i == j) ? 1.0 : vn[i];
                 if (sidx + 1 < kA) fetch(j - 1, vn);
-                const double t0 = (j < 32) ? readlane_f64(tl, j) : readlane_f64(tl2, j - 32);
-                const double t1 = (j < 32) ? readlane_f64(tl, 32 + j) : readlane_f64(tl2, j);
+                const int jq = j >> 5, jl = j & 31;                       // uniform
+                double tsel = tlq[0];
+#pragma unroll
+                for (int qq = 1; qq < RH; ++qq) tsel = (jq == qq) ? tlq[qq] : tsel;
+                const double t0 = readlane_f64(tsel, jl), t1 = readlane_f64(tsel, 32 + jl);
                 const double tj = half ? t1 : t0;
                 double dot = 0.0;
 #pragma unroll

@@ -346,6 +346,29 @@ def test_hybrid_pivoted_qr_matches_the_launch_per_step_form(m, n, t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,n,t,batch", [(169, 124, 105, 5), (141, 126, 122, 2), (150, 128, 100, 3), (200, 96, 70, 4)])
+def test_two_problem_waves_with_more_than_64_constraint_reflectors(m, n, t, batch):
+    """Batches whose J2 is narrow (n2 + 1 <= 32: two problems per wave in the pivot + solve stage, k_pivot_small2) while Q1 has MORE
+    THAN 64 reflectors (many active constraints, n <= 128): the side-by-side tail applies F_A.Q with all tau held in registers, one
+    word per 32 reflectors — a build that kept two words served reflectors 64.. with the other half-wave's tau (found by
+    tests/probes/fuzz_batched.py, seeds 61 / 62: ranks right, p wrong by 10-80 %).  Against the oracle, every problem of the batch."""
+    from enlsip_gn import GNSolver
+    s = GNSolver(device=0)
+    try:
+        probs = [synth.make_problem(88000 + 17 * k + m, m, n, t) for k in range(batch)]
+        refs = [go.gn_subproblem(J, rx, A, cx) for (J, rx, A, cx) in probs]
+        p, b, d, infos, jA, jL, jJ = s.solve_batched(np.stack([np.ascontiguousarray(J.T) for (J, _, _, _) in probs]),
+                                                     np.stack([rx for (_, rx, _, _) in probs]),
+                                                     np.stack([np.ascontiguousarray(A) for (_, _, A, _) in probs]),
+                                                     np.stack([cx for (_, _, _, cx) in probs]))
+        for k, ref in enumerate(refs):
+            assert (infos[k][0], infos[k][1], infos[k][2]) == (ref.rankA, ref.rankJ2, ref.code), k
+            assert rel(p[k], ref.p) <= 1e-9, (k, rel(p[k], ref.p))
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
 def test_fused_small_kernel_matches_the_two_launch_form():
     """One-tile problems with one narrow panel (C5's shape and neighbours): J*Q1 + panel in one launch (default) and as two launches
     (ENLSIP_GN_FUSE_SMALL=0) give the same factors, bit for bit — the fused kernel runs the same factorisation body on the same
