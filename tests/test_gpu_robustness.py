@@ -369,6 +369,21 @@ def test_two_problem_waves_with_more_than_64_constraint_reflectors(m, n, t, batc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("probe,count,seed", [("fuzz_batched", 30, 62), ("fuzz_gpu", 120, 71)])
+def test_randomised_shapes_against_the_oracle(probe, count, seed, monkeypatch):
+    """The randomised sweeps of tests/probes (mixed batches: full rank, rank-deficient A / J2, graded J2, zero A; single problems of
+    every size class) as part of the suite, one fixed seed each — seed 62 of the batched sweep is the one that found the defect
+    pinned by test_two_problem_waves_with_more_than_64_constraint_reflectors."""
+    import importlib.util, pathlib, sys
+    path = pathlib.Path(__file__).resolve().parent / "probes" / (probe + ".py")
+    spec = importlib.util.spec_from_file_location("probe_" + probe, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", [str(path), str(count), str(seed)])
+    assert mod.main() == 0
+
+
+@pytest.mark.gpu
 def test_fused_small_kernel_matches_the_two_launch_form():
     """One-tile problems with one narrow panel (C5's shape and neighbours): J*Q1 + panel in one launch (default) and as two launches
     (ENLSIP_GN_FUSE_SMALL=0) give the same factors, bit for bit — the fused kernel runs the same factorisation body on the same
