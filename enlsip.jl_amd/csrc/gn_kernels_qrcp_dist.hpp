@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void k_qd_init(QdArgs a) {
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 const int r = ln + 64 * i;
-                v[i] = src[r < kp ? r : 0];
+                // 64-row pieces that lie entirely below the diagonal of R0 are not fetched: their load re-reads piece 0 (a cache
+                // hit; the choice is wave-uniform) and the mask discards it
+                const int rs = (64 * i <= c || c >= n2) ? r : ln;
+                v[i] = src[rs < kp ? rs : 0];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
