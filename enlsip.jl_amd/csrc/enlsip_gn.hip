@@ -29,6 +29,7 @@
 #include "gn_kernels_qrcp_dist.hpp"
 #include "gn_kernels_qrcp_block.hpp"
 #include "gn_kernels_qrcp_block_reg.hpp"
+#include "gn_rescale.hpp"
 
 using namespace gn;
 
@@ -253,6 +254,10 @@ static void launch_constraint(int rows, int batch, hipStream_t s, ConstraintArgs
     if (launch_constraint_small(batch, s, a)) return;
     constraint_carve(a.n, a.t, a.fa_done, a.nv, a.blkd, a.gld, a.matd, a.need_T, a.fl_done);
     const size_t lds = constraint_lds_bytes(a.nv, a.blkd, a.gld, a.matd);
+    if (!a.fa_done && (size_t)a.n * a.t > (size_t)CMAT_DOUBLES) GN_ROUTE(ENLSIP_GN_ROUTE_CONSTRAINT_GLOBAL);
+    GN_ROUTE(rows <= 32 ? ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R1_256 : rows <= 64 ? ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R1_512 :
+             rows <= 128 ? ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R2 : rows <= 256 ? ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R4 :
+             rows <= 512 ? ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R8 : ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R16);
     if (rows <= 32) GN_LAUNCH_BIG((k_constraint<1, 8, 256>), dim3(batch), dim3(256), lds, s, a);
     else if (rows <= 64) GN_LAUNCH_BIG((k_constraint<1, 8, 512>), dim3(batch), dim3(512), lds, s, a);
     else if (rows <= 128) GN_LAUNCH_BIG((k_constraint<2, 8, 1024>), dim3(batch), dim3(1024), lds, s, a);
@@ -263,6 +268,9 @@ static void launch_constraint(int rows, int batch, hipStream_t s, ConstraintArgs
 static void launch_pivot(int rows, int batch, hipStream_t s, FinalArgs a) {
     final_carve(a.m, a.n, a.t, a.nv, a.matd);
     const size_t lds = final_lds_bytes(a.nv, a.matd);
+    GN_ROUTE(rows <= 32 ? ENLSIP_GN_ROUTE_PIVOT_LDS_R1_256 : rows <= 64 ? ENLSIP_GN_ROUTE_PIVOT_LDS_R1_512 :
+             rows <= 128 ? ENLSIP_GN_ROUTE_PIVOT_LDS_R2 : rows <= 256 ? ENLSIP_GN_ROUTE_PIVOT_LDS_R4 :
+             rows <= 512 ? ENLSIP_GN_ROUTE_PIVOT_LDS_R8 : ENLSIP_GN_ROUTE_PIVOT_LDS_R16);
     if (rows <= 32) GN_LAUNCH_BIG((k_pivot_solve<1, 8, 256>), dim3(batch), dim3(256), lds, s, a);
     else if (rows <= 64) GN_LAUNCH_BIG((k_pivot_solve<1, 8, 512>), dim3(batch), dim3(512), lds, s, a);
     else if (rows <= 128) GN_LAUNCH_BIG((k_pivot_solve<2, 8, 1024>), dim3(batch), dim3(1024), lds, s, a);
@@ -282,7 +290,8 @@ static CaqrArgs caqr_args(enlsip_gn_handle h, int k, const LevelPlan& L) {
     return a;
 }
 
-static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
+static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     dim3 grid(groups, (unsigned)h->plan.batch);
     // one-tile problems of at most 256 rows: 4 waves x 8 columns issue ~20 % fewer instructions per step than 8 x 4
     // (measured on C5: panel stage 0.63 -> 0.57 ms); everywhere else the 8-wave form wins (a 16-wave form: 8.1 -> 11.2 ms)
@@ -292,7 +301,7 @@ static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
         // nothing (the geometry of a node is the same in every form: slot ln + 64 i = block (ln >> 5) + 2 i)
         int rpl = h->plan.RPL;
         if (rpl == 8 && ((h->factor_nw4 >= 1 && a.level == 0) || h->factor_nw4 >= 2)) {      // A/B: 4 waves x 8 columns
-            hipLaunchKernelGGL((k_caqr_factor<8, 4>), grid, dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL((k_caqr_factor<8, 4>), grid, dim3(256), 0, st, a);
             return;
         }
         if (a.level > 0 && groups == 1) {
@@ -300,13 +309,13 @@ static void launch_factor(enlsip_gn_handle h, const CaqrArgs& a, int groups) {
             const int fit = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 8));
             if (fit < rpl) rpl = fit;
         }
-        if (rpl == 8) hipLaunchKernelGGL((k_caqr_factor<8, 8>), grid, dim3(512), 0, h->stream, a);
-        else if (rpl == 4) hipLaunchKernelGGL((k_caqr_factor<4, 8>), grid, dim3(512), 0, h->stream, a);
-        else if (rpl == 2) hipLaunchKernelGGL((k_caqr_factor<2, 8>), grid, dim3(512), 0, h->stream, a);
-        else hipLaunchKernelGGL((k_caqr_factor<1, 8>), grid, dim3(512), 0, h->stream, a);
+        if (rpl == 8) hipLaunchKernelGGL((k_caqr_factor<8, 8>), grid, dim3(512), 0, st, a);
+        else if (rpl == 4) hipLaunchKernelGGL((k_caqr_factor<4, 8>), grid, dim3(512), 0, st, a);
+        else if (rpl == 2) hipLaunchKernelGGL((k_caqr_factor<2, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_caqr_factor<1, 8>), grid, dim3(512), 0, st, a);
     } else {
-        if (h->plan.RPL == 8) hipLaunchKernelGGL((k_caqr_factor<8, 4>), grid, dim3(256), 0, h->stream, a);
-        else hipLaunchKernelGGL((k_caqr_factor<4, 4>), grid, dim3(256), 0, h->stream, a);
+        if (h->plan.RPL == 8) hipLaunchKernelGGL((k_caqr_factor<8, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_caqr_factor<4, 4>), grid, dim3(256), 0, st, a);
     }
 }
 static void launch_update_refl(enlsip_gn_handle h, const CaqrArgs& a, int groups, int ncols) {
@@ -337,6 +346,8 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
     const int npan = (kp_launch + PB - 1) / PB;
     const bool use_mfma = !(h->flags & ENLSIP_GN_UPDATE_REFLECTORS);
+    GN_ROUTE(P.RPL == 8 ? ENLSIP_GN_ROUTE_SWEEP_TILE512 : ENLSIP_GN_ROUTE_SWEEP_TILE256);
+    if (!use_mfma) GN_ROUTE(ENLSIP_GN_ROUTE_SWEEP_REFLECTORS);
     const double mpad = (double)rup(std::max<long long>(P.m, 1), 32);
     // the launch shape is the widest J2 of the batch; narrower ones exist only when some constraint matrix was rank deficient
     // (second attempt of solve_dev) or when the caller's problems differ
@@ -432,12 +443,30 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             GN_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
         }
         sB = h->stream2;
+        GN_ROUTE(ENLSIP_GN_ROUTE_SWEEP_LOOKAHEAD);
     }
+    // Deep look-ahead (round 5, paired sweeps only): the chain of a pair is itself a small task graph, and three of its edges do not
+    // exist — the tree of the first panel only needs that panel's tile factors, so it runs BESIDE the update of the second panel's
+    // columns and that panel's tile factorisation; the pair pass over the next pair's columns only needs the two tile factorisations,
+    // so it runs beside the second panel's tree; and the next pair's first panel only needs the FIRST 32 of those 64 columns, so
+    // the updates of the other 32 run beside its factorisation.  Two more streams (sC, sD), events for the edges.  Per pair of
+    // C4 the chain was 1.27 ms of 19 launches in a row (profiles/r4_notes.md, last section).
+    const bool deep = la && h->la_deep;
+    hipStream_t sC = nullptr, sD = nullptr;
+    if (deep) {
+        if (!h->stream3) GN_HIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+        if (!h->stream4) GN_HIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+        sC = h->stream3;
+        sD = h->stream4;
+    }
+    hipEvent_t deep_c = nullptr, deep_d = nullptr;      // last work on sC / sD this stream has not waited for yet
     auto la_join = [&]() -> int {                 // this stream goes on only after the second stream's last far update
         if (la_prev) {
             GN_HIP(hipStreamWaitEvent(sA, la_prev, 0));
             la_prev = nullptr;
         }
+        if (deep_c) { GN_HIP(hipStreamWaitEvent(sA, deep_c, 0)); deep_c = nullptr; }
+        if (deep_d) { GN_HIP(hipStreamWaitEvent(sA, deep_d, 0)); deep_d = nullptr; }
         return 0;
     };
     for (int k = 0; k < npan;) {
@@ -447,6 +476,8 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         if (h->profiling && ntrail > 0) h->upd_all_bytes += (double)P.batch * btrail(k, ntrail);   // every column right of the panel
         if (P.pair && use_mfma && !(k & 1) && k + 1 < npan) {
             // ---- panel pair (k, k + 1): tiles shared, ONE pass over the far trailing columns for both (gn_kernels_caqr.hpp) ----
+            GN_ROUTE(ENLSIP_GN_ROUTE_SWEEP_PAIRS);
+            if (P.panels[k].levels.size() > 1) GN_ROUTE(ENLSIP_GN_ROUTE_SWEEP_TREE);
             const int kb = k + 1;
             const auto& LA = P.panels[k].levels;
             const auto& LB = P.panels[kb].levels;
@@ -461,6 +492,96 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             // far launches of pairs 1, 3, 5 of a C2 step (profiles/r4_notes.md).  The exact grid has an odd y extent.
             const int far_grid = mixed ? ntrail : nfar;
             auto live = [&](int st) { return h->debug_stage < 0 || st <= h->debug_stage; };   // ENLSIP_GN_DEBUG_STAGE (debugging aid)
+            if (deep) {
+                // segments of the far window: the next pair's first panel [0, 32), its second panel [32, 64), the rest
+                const int na = std::min(PB, nfar), nb = std::min(PB, nfar - na), nrest = nfar - na - nb;
+                auto ev = [&](hipEvent_t& e, hipStream_t st) -> int {
+                    if (int rc = la_event(e)) return rc;
+                    GN_HIP(hipEventRecord(e, st));
+                    return 0;
+                };
+                auto far_l0 = [&](int sub0, int ncw, hipStream_t st) -> int {        // both level-0 reflectors on far columns [sub0, sub0 + ncw)
+                    CaqrArgs a = caqr_args(h, k, LA[0]);
+                    a.win = 2; a.pair = 1; a.tOff2 = LB[0].tOff; a.sub0 = sub0; a.subn = ncw;
+                    const bool has_rhs = (sub0 + ncw == nfar);
+                    return timed(btrail(k, ncw) + btrail(kb, ncw), st, [&] {
+                        if (has_rhs) update_l0(a, LA[0], ncw, ncw, st);
+                        else launch_update_v4(h->plan.RPL, a, LA[0].groups, ncw, (int)P.batch, st);
+                    });
+                };
+                auto far_tree = [&](int kk, const std::vector<LevelPlan>& LV, int win, int sub0, int ncw, hipStream_t st) -> int {
+                    for (size_t li = 1; li < LV.size(); ++li) {
+                        CaqrArgs t = caqr_args(h, kk, LV[li]);
+                        t.win = win; t.sub0 = sub0; t.subn = ncw;
+                        if (int rc2 = other(st, [&] { launch_update_v4(h->plan.RPL, t, LV[li].groups, ncw, (int)P.batch, st); })) return rc2;
+                    }
+                    return 0;
+                };
+                hipEvent_t eA, eB, eC, eE, eF, eNa, e2 = nullptr;
+                // sA: tile factorisation of the first panel (everything of the previous pair on its 32 columns ran on sA)
+                { CaqrArgs a = caqr_args(h, k, LA[0]); launch_factor(h, a, LA[0].groups, sA); }
+                if (int rc = ev(eA, sA)) return rc;
+                // sA: ... applied to the second panel's columns (the previous pair's updates of THOSE columns ran on sD)
+                if (deep_d) { GN_HIP(hipStreamWaitEvent(sA, deep_d, 0)); deep_d = nullptr; }
+                {
+                    CaqrArgs a = caqr_args(h, k, LA[0]);
+                    a.win = 1;
+                    if (int rc = other(sA, [&] { launch_update_v4(h->plan.RPL, a, LA[0].groups, bwb, (int)P.batch, sA); })) return rc;
+                }
+                if (int rc = ev(eB, sA)) return rc;
+                // sC: the first panel's tree, each level applied to the second panel's columns (rows 0..31 of the tiles) — beside
+                //     sA: the second panel's tile factorisation (rows 32.. of the tiles)
+                GN_HIP(hipStreamWaitEvent(sC, eA, 0));
+                for (size_t li = 1; li < LA.size(); ++li) {
+                    CaqrArgs a = caqr_args(h, k, LA[li]);
+                    launch_factor(h, a, LA[li].groups, sC);
+                    if (li == 1) GN_HIP(hipStreamWaitEvent(sC, eB, 0));
+                    a.win = 1;
+                    if (int rc = other(sC, [&] { launch_update_v4(h->plan.RPL, a, LA[li].groups, bwb, (int)P.batch, sC); })) return rc;
+                }
+                if (int rc = ev(eE, sC)) return rc;
+                { CaqrArgs a = caqr_args(h, kb, LB[0]); launch_factor(h, a, LB[0].groups, sA); }
+                if (int rc = ev(eC, sA)) return rc;
+                // sA: the second panel's tree (needs the first panel's tree on its columns) — beside
+                // sC: the pair pass over the next pair's FIRST panel (needs both tile factorisations and the previous pair's rest)
+                GN_HIP(hipStreamWaitEvent(sA, eE, 0));
+                for (size_t li = 1; li < LB.size(); ++li) {
+                    CaqrArgs a = caqr_args(h, kb, LB[li]);
+                    launch_factor(h, a, LB[li].groups, sA);
+                }
+                if (int rc = ev(eF, sA)) return rc;
+                GN_HIP(hipStreamWaitEvent(sC, eC, 0));
+                if (la_prev) GN_HIP(hipStreamWaitEvent(sC, la_prev, 0));
+                if (int rc = far_l0(0, na, sC)) return rc;
+                if (int rc = ev(eNa, sC)) return rc;
+                // sD: the next pair's SECOND panel: pair pass, then both trees — beside everything that follows on sA up to the
+                //     next pair's update of those columns
+                if (nb > 0) {
+                    GN_HIP(hipStreamWaitEvent(sD, eC, 0));
+                    if (la_prev) GN_HIP(hipStreamWaitEvent(sD, la_prev, 0));
+                    if (int rc = far_l0(na, nb, sD)) return rc;
+                    GN_HIP(hipStreamWaitEvent(sD, eF, 0));                   // (eF follows eE on sA: both trees are complete)
+                    if (int rc = far_tree(k, LA, 2, na, nb, sD)) return rc;
+                    if (int rc = far_tree(kb, LB, 0, na, nb, sD)) return rc;
+                    if (int rc = ev(deep_d, sD)) return rc;
+                }
+                // sA: both trees on the next pair's first panel: the next tile factorisation follows on this stream
+                GN_HIP(hipStreamWaitEvent(sA, eNa, 0));
+                if (int rc = far_tree(k, LA, 2, 0, na, sA)) return rc;
+                if (int rc = far_tree(kb, LB, 0, 0, na, sA)) return rc;
+                // sB: the rest of the far window (lowest priority, the bulk of the flops)
+                if (nrest > 0) {
+                    GN_HIP(hipStreamWaitEvent(sB, eF, 0));
+                    if (int rc = far_l0(na + nb, nrest, sB)) return rc;
+                    if (int rc = far_tree(k, LA, 2, na + nb, nrest, sB)) return rc;
+                    if (int rc = far_tree(kb, LB, 0, na + nb, nrest, sB)) return rc;
+                    if (int rc = ev(e2, sB)) return rc;
+                }
+                la_prev = e2;          // nullptr when nothing was left for sB: its earlier work has been waited for by sC / sD
+                deep_c = nullptr;      // sC's last work (eNa) has been waited for on sA
+                k += 2;
+                continue;
+            }
             if (live(0)) {   // level 0 of the first panel, applied to the second panel's columns only
                 CaqrArgs a = caqr_args(h, k, LA[0]);
                 launch_factor(h, a, LA[0].groups);
@@ -560,6 +681,8 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         // ---- one panel ----
         // last panel narrower than 32 with d as the only trailing column: d rides through the factor kernels
         const bool passenger = (ntrail == 1 && bwk < PB && kp_launch == n2_launch);
+        GN_ROUTE(passenger ? ENLSIP_GN_ROUTE_SWEEP_PASSENGER : ENLSIP_GN_ROUTE_SWEEP_PLAIN);
+        if (P.panels[k].levels.size() > 1) GN_ROUTE(ENLSIP_GN_ROUTE_SWEEP_TREE);
         if (lap && !passenger && ntrail > 0) {
             const auto& LV = P.panels[k].levels;
             for (const LevelPlan& L : LV) {                      // every factorisation of the panel first
@@ -640,6 +763,7 @@ static int run_qrcp_dist(enlsip_gn_handle h, int n2_launch) {
     a.n2cap = n2_launch;
     const int G = (n2_launch + 1 + QD_CPW - 1) / QD_CPW;
     dim3 grid(G, (unsigned)P.batch);
+    GN_ROUTE(ENLSIP_GN_ROUTE_PIVOT_STEPS);
     const bool big = kp_launch > 512;
     if (big) hipLaunchKernelGGL(k_qd_init<16>, grid, dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL(k_qd_init<8>, grid, dim3(256), 0, h->stream, a);
@@ -663,6 +787,7 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     const int kp_launch = (int)std::min<long long>(P.m, n2_launch);
     int jhead = kp_launch > 512 ? kp_launch - 512 : 0;
     jhead += jhead & 1;
+    GN_ROUTE(jhead > 0 ? ENLSIP_GN_ROUTE_PIVOT_HYBRID : ENLSIP_GN_ROUTE_PIVOT_BLOCKS);
     SbArgs a{};
     QdArgs& q = a.q;
     q.n = (int)P.n; q.ldw = P.ldw; q.ldr = P.ldr; q.step = -1; q.prob0 = 0;
@@ -712,17 +837,25 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
     // solve in steady state), later chunks are small
     int chunk = std::min(kp_blk, h->sb_hint > 0 ? h->sb_hint : kp_blk / 16 + 4);
     SbInfo* hinfo = (SbInfo*)h->h_sbinfo;
-    while (it < kp_blk) {
-        for (int i = 0; i < chunk && it < kp_blk; ++i, ++it) {
+    // rows_bound: an upper bound of kp - j0 over the problems.  A block in which EVERY form the bound asks for was launched
+    // serves every unfinished problem, and a served problem makes at least one step: the bound then falls by one.  A block
+    // in which the hints suppressed one of those forms may have left a problem unserved: the bound stays, and the read-back
+    // at the end of the chunk replaces it by the exact maximum.  (Until round 5 the forms were gated on kp_blk - it, which
+    // assumes a step per block for everybody: a problem that a hinted chunk had left behind above 256 rows was never served
+    // once kp_blk - it had fallen to 256, and the loop ran out with wrong factors.)
+    int rows_bound = kp_blk;
+    const int max_blocks = 2 * kp_blk + 64;         // without hints kp_blk blocks always suffice; hinted chunks may idle
+    bool done = kp_blk <= 0;
+    while (!done) {
+        for (int i = 0; i < chunk && rows_bound > 0; ++i, ++it) {
             a.blkid = it;
             GN_TRACE(h, "  qrcp block %d", it);
             // candidates in the registers of one workgroup (kp <= 512), block reflector applied to the still-active columns.
             // Up to three forms per block, each problem runs in the one that fits its current row count kp - j0
-            // (gn_kernels_qrcp_block_reg.hpp); after `it` blocks every problem has made at least `it` steps, so the large
-            // forms are no longer launched once kp_launch - it fits a smaller one.
-            const int rows_max = kp_blk - it;
+            // (gn_kernels_qrcp_block_reg.hpp): the large forms are no longer launched once the bound fits a smaller one.
             const dim3 fg((unsigned)P.batch);
-            bool big = rows_max > 256, med = rows_max > 128, small = true;
+            const bool big0 = rows_bound > 256, med0 = rows_bound > 128;
+            bool big = big0, med = med0, small = true;
             if (hints && it < (int)h->sb_rows_max.size() && h->sb_rows_max[it] > 0) {
                 // what the previous solve saw at this block id, widened by a block's worth of steps either way
                 const int lo = h->sb_rows_min[it] - 32, hi = h->sb_rows_max[it] + 32;
@@ -731,21 +864,30 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
                 small = lo <= 128;
             }
             if (big) {
+                GN_ROUTE(kp_blk <= 448 ? ENLSIP_GN_ROUTE_PIVOT_BLOCKS_448 : ENLSIP_GN_ROUTE_PIVOT_BLOCKS_512);
                 if (kp_blk <= 448) hipLaunchKernelGGL((k_sb_factor_reg<7, 8, 4>), fg, dim3(512), 0, s, a);
                 else hipLaunchKernelGGL((k_sb_factor_reg<8, 8, 4>), fg, dim3(512), 0, s, a);
             }
-            if (med) hipLaunchKernelGGL((k_sb_factor_reg<4, 8, 2>), fg, dim3(512), 0, s, a);
-            if (small) hipLaunchKernelGGL((k_sb_factor_reg<2, 8, 0>), fg, dim3(512), 0, s, a);
+            if (med) { GN_ROUTE(ENLSIP_GN_ROUTE_PIVOT_BLOCKS_256); hipLaunchKernelGGL((k_sb_factor_reg<4, 8, 2>), fg, dim3(512), 0, s, a); }
+            if (small) { GN_ROUTE(ENLSIP_GN_ROUTE_PIVOT_BLOCKS_128); hipLaunchKernelGGL((k_sb_factor_reg<2, 8, 0>), fg, dim3(512), 0, s, a); }
             hipLaunchKernelGGL(k_sb_update_blk, ugrid, dim3(256), 0, s, a);
+            if (big == big0 && med == med0 && small) --rows_bound;
         }
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(hinfo, h->sbInfo, (size_t)P.batch * sizeof(SbInfo), hipMemcpyDeviceToHost, s));
         GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)P.batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
         GN_HIP(hipMemcpyAsync(h->h_sb_stat, h->sb_stat.p, 2 * SB_STAT_BLKS * sizeof(int), hipMemcpyDeviceToHost, s));
         GN_HIP(hipStreamSynchronize(s));
-        bool done = true;
-        for (long long k = 0; k < P.batch; ++k)
-            done = done && (h->h_state[k].n2 > n2_launch || hinfo[k].j0 >= h->h_state[k].kp);   // wider problems are skipped here
+        done = true;
+        int rows_left = 0;                       // exact maximum of kp - j0 over the unfinished problems
+        for (long long k = 0; k < P.batch; ++k) {
+            if (h->h_state[k].n2 > n2_launch) continue;            // wider problems are skipped here
+            const int left = h->h_state[k].kp - hinfo[k].j0;
+            if (left > 0) {
+                done = false;
+                rows_left = std::max(rows_left, left);
+            }
+        }
         if (done) {
             int used = 0;
             for (long long k = 0; k < P.batch; ++k) used = std::max(used, hinfo[k].blk + 1);
@@ -769,12 +911,95 @@ static int run_qrcp_block(enlsip_gn_handle h, int n2_launch) {
             h->sb_rows_batch = P.batch;
             break;
         }
+        if (it >= max_blocks) {
+            // cannot happen with every form launched (a served problem makes a step per block); never assemble half-done factors
+            h->sb_rows_max.clear();
+            h->sb_rows_min.clear();
+            h->sb_rows_kp = -1;
+            h->err = "blocked pivoted QR of R0 did not finish within its block budget";
+            return 996;
+        }
         hints = false;          // somebody is not done: the rest of the stage launches every form
         fell_back = true;
+        rows_bound = std::min(rows_left, 512);
         chunk = 4;
     }
     hipLaunchKernelGGL(k_qd_assemble, grid, dim3(256), 0, s, q);
     GN_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rescale path (gn_rescale.hpp): scale the resident factors of ONE problem back to the caller's data
+// ---------------------------------------------------------------------------------------------
+static void scale_region(hipStream_t s, double* X, long long ld, long long rows, long long cols, int shift, int upper) {
+    if (rows <= 0 || cols <= 0 || shift == 0) return;
+    hipLaunchKernelGGL(k_scale_region, dim3((unsigned)std::min<long long>((rows + 255) / 256, 1024), (unsigned)cols), dim3(256), 0, s,
+                       X, ld, (int)rows, (int)cols, shift, upper);
+}
+// F_A.R, F_L11.R, b (and the pieces the distributed constraint stage keeps for the re-solve): x 2^-sc_eA.  p1, every tau, every
+// reflector vector and the T blocks of Q1 do not depend on the scale.
+static int unscale_constraint_side(enlsip_gn_handle h) {
+    const Plan& P = h->plan;
+    hipStream_t s = h->stream;
+    const int sh = -h->sc_eA;
+    scale_region(s, h->FA, P.n, P.kA, P.t, sh, 1);
+    scale_region(s, h->FL, P.t, std::min<long long>(P.t, P.kA), P.kA, sh, 1);
+    scale_region(s, h->bvec, P.t, P.t, 1, sh, 0);
+    if (h->cdist.valid) {
+        scale_region(s, const_cast<double*>(h->cdist.L), h->cdist.ldL, P.t, P.kA, sh, 0);
+        scale_region(s, const_cast<double*>(h->cdist.qb), P.t, P.t, 1, sh, 0);
+    }
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+// J1 = (J*Q1)[:, 1:rankA], the carried right-hand side d, the pivoted factor R of J2 with its carried column, the saved leading
+// entries of Q0'd, and the outputs d (device): x 2^-sc_eJ.  (R0 inside W is consumed by the pivoted QR only; V and T of the CAQR
+// and of the pivoted QR do not depend on the scale.)
+static int unscale_jacobian_side(enlsip_gn_handle h, double* dd) {
+    const Plan& P = h->plan;
+    hipStream_t s = h->stream;
+    const int sh = -h->sc_eJ;
+    const ProbState& st = h->h_state[0];
+    scale_region(s, h->W, P.ldw, P.ldw, st.rankA, sh, 0);
+    scale_region(s, h->W + (size_t)P.n * P.ldw, P.ldw, P.ldw, 1, sh, 0);
+    scale_region(s, h->Rt, P.ldr, st.kp, st.n2, sh, 1);
+    scale_region(s, h->Rt + (size_t)st.n2 * P.ldr, P.ldr, st.kp, 1, sh, 0);
+    scale_region(s, h->zsave, P.ldr, st.kp, 1, sh, 0);
+    scale_region(s, h->qdDiag, P.ldr, st.kp, 1, sh, 0);
+    if (dd) scale_region(s, dd, P.m, P.m, 1, sh, 0);
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+// largest |entry| of the four inputs of problem 0 of a one-problem solve -> power-of-two shifts that bring J, rx / A', cx to
+// magnitude ~1 (0: inside the band, zero, or not finite — nothing to rescale)
+static int extreme_shifts(enlsip_gn_handle h, long long m, long long n, long long t, const double* dJ, long long ldj, const double* drx,
+                          const double* dAt, long long ldat, const double* dcx, int* shiftJ, int* shiftA) {
+    hipStream_t s = h->stream;
+    unsigned long long* dmx = (unsigned long long*)(h->small + 32);      // 2 words of the handle's 256-byte scalar area
+    GN_HIP(hipMemsetAsync(dmx, 0, 16, s));
+    if (dJ && drx) {
+        hipLaunchKernelGGL(k_amax_bits, dim3((unsigned)n), dim3(256), 0, s, dJ, ldj, (int)m, (int)n, dmx);
+        hipLaunchKernelGGL(k_amax_bits, dim3(1), dim3(256), 0, s, drx, m, (int)m, 1, dmx);
+    }
+    if (t > 0 && dAt && dcx) {
+        hipLaunchKernelGGL(k_amax_bits, dim3((unsigned)t), dim3(256), 0, s, dAt, ldat, (int)n, (int)t, dmx + 1);
+        hipLaunchKernelGGL(k_amax_bits, dim3(1), dim3(256), 0, s, dcx, t, (int)t, 1, dmx + 1);
+    }
+    GN_HIP(hipGetLastError());
+    unsigned long long hb[2] = {0, 0};
+    GN_HIP(hipMemcpyAsync(hb, dmx, 16, hipMemcpyDeviceToHost, s));
+    GN_HIP(hipStreamSynchronize(s));
+    auto shift_of = [](unsigned long long bits) -> int {
+        double a;
+        memcpy(&a, &bits, 8);
+        if (!(a > 0.0) || !std::isfinite(a)) return 0;
+        int e;
+        (void)std::frexp(a, &e);                    // a = f 2^e, 0.5 <= f < 1
+        return (e > GN_RESCALE_BAND || e < -GN_RESCALE_BAND) ? -(e - 1) : 0;
+    };
+    *shiftJ = shift_of(hb[0]);
+    *shiftA = shift_of(hb[1]);
     return 0;
 }
 
@@ -869,8 +1094,13 @@ static int run_constraint_stage(enlsip_gn_handle h, long long batch, long long m
     const Plan& P = h->plan;
     hipStream_t s = h->stream;
     if (prob0 == 0 && code_ov == 0) h->cdist.valid = false;
+    // the resident problem was rescaled (sc_eA != 0: one problem): the stage runs on the scaled copies of A', cx with the absolute
+    // rank threshold scaled alike, and what it leaves resident is scaled back below
+    const bool scaledA = h->sc_eA != 0 && batch == 1 && prob0 == 0 && t > 0;
+    if (scaledA) { dAt = h->rs_At; ldat = n; strideAt = n * t; dcx = h->rs_cx; }
     ConstraintArgs ca{};
     ca.n = (int)n; ca.t = (int)t; ca.kA = P.kA; ca.m = (int)m; ca.eps_rank = eps_rank;
+    ca.abs_shift = scaledA ? h->sc_eA : 0;
     ca.dimA_override = (int)dimA_ov; ca.code_override = code_ov; ca.prob0 = prob0;
     ca.At = dAt; ca.ldat = ldat; ca.strideAt = strideAt; ca.cx = dcx; ca.stride_cx = t;
     ca.FA = h->FA; ca.sFA = P.sFA; ca.tauA = h->tauA; ca.sTauA = P.sTauA; ca.jpvtA = h->jpvtA; ca.sJA = P.sJA;
@@ -878,13 +1108,19 @@ static int run_constraint_stage(enlsip_gn_handle h, long long batch, long long m
     ca.TA = h->TA; ca.sTA = P.sTA; ca.p1 = h->p1; ca.sP1 = P.sP1; ca.bvec = h->bvec; ca.sB = P.sB;
     ca.state = h->state;
     // many constraints: both factorisations through the distributed pivoted QR
-    if (t > 64 && (size_t)n * t > (size_t)CMAT_DOUBLES) return run_constraint_dist(h, ca, batch, n, t);
+    if (t > 64 && (size_t)n * t > (size_t)CMAT_DOUBLES) {
+        GN_ROUTE(ENLSIP_GN_ROUTE_CONSTRAINT_DIST);
+        int rcd = run_constraint_dist(h, ca, batch, n, t);
+        if (rcd) return rcd;
+        return scaledA ? unscale_constraint_side(h) : 0;
+    }
     // F_A of a matrix that does not fit the LDS area of k_constraint: whole matrix in registers (gn_kernels_geqp3_reg.hpp)
     if (t >= 1 && t <= 64 && n <= 512 && (size_t)n * t > (size_t)CMAT_DOUBLES) {
         Geqp3RegArgs ga{};
         ga.rows = (int)n; ga.cols = (int)t; ga.A = dAt; ga.lda = ldat; ga.strideA = strideAt;
         ga.F = h->FA; ga.sF = P.sFA; ga.tau = h->tauA; ga.sTau = P.sTauA; ga.jpvt = h->jpvtA; ga.sJ = P.sJA;
         ga.T = h->TA; ga.sT = P.sTA; ga.prob0 = prob0;
+        GN_ROUTE(n <= 256 ? ENLSIP_GN_ROUTE_CONSTRAINT_REG4 : ENLSIP_GN_ROUTE_CONSTRAINT_REG8);
         if (n <= 256) hipLaunchKernelGGL(k_geqp3_reg<4>, dim3((unsigned)batch), dim3(512), 0, s, ga);
         else hipLaunchKernelGGL(k_geqp3_reg<8>, dim3((unsigned)batch), dim3(512), 0, s, ga);
         ca.fa_done = 1;
@@ -892,7 +1128,7 @@ static int run_constraint_stage(enlsip_gn_handle h, long long batch, long long m
     // with F_A done the kernel only factors the t x kA matrix R_A': size its rows-per-lane instantiation (and LDS) for that
     launch_constraint(ca.fa_done ? (int)std::max<long long>(t, 1) : (int)std::max(n, t), (int)batch, s, ca);
     GN_HIP(hipGetLastError());
-    return 0;
+    return scaledA ? unscale_constraint_side(h) : 0;
 }
 
 static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long n, long long t,
@@ -903,6 +1139,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
                      long long* djA, long long* djL, long long* djJ, enlsip_gn_info* hinfo = nullptr) {
     h->split = 0;   // routing of accessors to the pipeline child is (re)established by the batched entry point
     h->chunk0 = 0;  // ... and to the resident chunk by solve_chunked
+    gn_route_acc = 0;
     const bool reuse = h->reuse_once;
     h->reuse_once = false;
     const bool upper_in = h->upper_once && t == 0 && m <= n;      // J is upper triangular (and unconstrained): it IS its own R0, Q0 = I
@@ -921,6 +1158,9 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
     h->last_rx = drx; h->last_stride_rx = m;
     h->last_cx = dcx; h->last_stride_cx = t;
     h->last_At = dAt; h->last_ldat = ldat; h->last_strideAt = strideAt;
+    h->sc_eJ = 0;
+    if (!reuse) h->sc_eA = 0;       // (a resident constraint stage keeps the scale enlsip_gn_factor_constraints gave it)
+    h->rescue_prob.clear();
     hipStream_t s = h->stream;
     if (h->profiling) {
         if (!h->ev_ready) {
@@ -946,6 +1186,8 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
     mark(1);
     GN_TRACE(h, "constraint stage done");
 
+    // steps 2-4 for the Jacobian side given (the caller's J, rx — or their scaled copies, abs_shift = their power of two)
+    auto attempts = [&](const double* dJ, long long ldj, long long strideJ, const double* drx, int abs_shift) -> int {
     int n2_launch = (int)(n - P.kA);  // speculate rankA = min(n, t); verified after the solve
     for (int attempt = 0; attempt < 2; ++attempt) {
         // 2. JQ1 = J*Q1, d_temp
@@ -975,12 +1217,14 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
             rc = run_caqr(h, n2_launch);
             if (rc) return rc;
         }
+        if (upper_in) GN_ROUTE(ENLSIP_GN_ROUTE_SWEEP_UPPER_INPUT);
+        if (attempt > 0) GN_ROUTE(ENLSIP_GN_ROUTE_SECOND_ATTEMPT);
         mark(3);
         GN_TRACE(h, "CAQR done");
         // 4. pivoted QR of R0 + solves + outputs
         FinalArgs fa{};
         fa.m = (int)m; fa.n = (int)n; fa.t = (int)t; fa.kA = P.kA; fa.ldw = P.ldw; fa.ldr = P.ldr;
-        fa.eps_rank = eps_rank; fa.dimJ2_override = (int)dimJ2_ov; fa.refactor = 1;
+        fa.eps_rank = eps_rank; fa.abs_shift = abs_shift; fa.dimJ2_override = (int)dimJ2_ov; fa.refactor = 1;
         fa.W = h->W; fa.sW = P.sW; fa.Rt = h->Rt; fa.sRt = P.sRt; fa.tauJ = h->tauJ; fa.sTauJ = P.sTauJ;
         fa.jpvtJ = h->jpvtJ; fa.sJJ = P.sJJ; fa.FA = h->FA; fa.sFA = P.sFA; fa.tauA = h->tauA; fa.sTauA = P.sTauA;
         fa.p1 = h->p1; fa.sP1 = P.sP1; fa.bvec = h->bvec; fa.sB = P.sB; fa.zsave = h->zsave; fa.sZ = P.sZ;
@@ -1005,6 +1249,10 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
             launch_pivot((int)std::min<long long>(m, n), (int)batch, s, fa);
         mark(4);
         GN_TRACE(h, "final kernel done");
+        // nominate problems whose largest column norm overflowed or sits at the bottom of the exponent range (gn_rescale.hpp)
+        if (h->rescale_enabled)
+            hipLaunchKernelGGL(k_extreme_flags, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, s, h->state, (const double*)h->Rt, P.sRt,
+                               (const double*)h->FA, P.sFA, P.kA, n2_launch, (int)batch);
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(h->h_state, h->state, (size_t)batch * sizeof(ProbState), hipMemcpyDeviceToHost, s));
         GN_HIP(hipStreamSynchronize(s));
@@ -1012,6 +1260,90 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         for (long long k = 0; k < batch; ++k) n2max = std::max(n2max, h->h_state[k].n2);
         if (n2max <= n2_launch) break;
         n2_launch = n2max;  // some A was rank deficient: J2 is wider than speculated, redo from J*Q1
+    }
+    return 0;
+    };
+    rc = attempts(dJ, ldj, strideJ, drx, 0);
+    if (rc) return rc;
+    // ---- magnitudes beyond the range of plain sums of squares: LAPACK's result through a power-of-two scaling (gn_rescale.hpp) ----
+    {
+        const int fl = GN_FLAG_NONFINITE | GN_FLAG_TINY;
+        bool flagged = false;
+        for (long long k = 0; k < batch; ++k) flagged = flagged || (h->h_state[k].status & fl);
+        if (flagged && batch == 1) {
+            int sJ = 0, sA = 0;
+            rc = extreme_shifts(h, m, n, t, dJ, ldj, drx, reuse ? nullptr : dAt, ldat, reuse ? nullptr : dcx, &sJ, &sA);
+            if (rc) return rc;
+            if (sJ || sA) {
+                GN_TRACE(h, "rescale: J, rx by 2^%d, A', cx by 2^%d", sJ, sA);
+                const size_t nJ = (size_t)m * n, nA = (size_t)n * t;
+                rc = grow(h, h->rs_buf, (nJ + (size_t)m + nA + (size_t)t + 8) * 8);
+                if (rc) return rc;
+                h->rs_J = (double*)h->rs_buf.p; h->rs_rx = h->rs_J + nJ; h->rs_At = h->rs_rx + m; h->rs_cx = h->rs_At + nA;
+                auto copy_scaled = [&](double* dst, long long ldd, const double* src, long long lds, long long rows, long long cols, int sh) {
+                    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)std::min<long long>((rows + 255) / 256, 1024), (unsigned)cols), dim3(256), 0, s,
+                                       dst, ldd, src, lds, (int)rows, (int)cols, sh);
+                };
+                if (sJ) {
+                    copy_scaled(h->rs_J, m, dJ, ldj, m, n, sJ);
+                    copy_scaled(h->rs_rx, m, drx, m, m, 1, sJ);
+                }
+                if (sA) {
+                    copy_scaled(h->rs_At, n, dAt, ldat, n, t, sA);
+                    copy_scaled(h->rs_cx, t, dcx, t, t, 1, sA);
+                    h->sc_eA = sA;
+                    rc = run_constraint_stage(h, 1, m, n, t, dAt, ldat, strideAt, dcx, eps_rank, dimA_ov);     // on the scaled copies; scaled back
+                    if (rc) return rc;
+                }
+                h->sc_eJ = sJ;
+                rc = attempts(sJ ? h->rs_J : dJ, sJ ? m : ldj, sJ ? (long long)nJ : strideJ, sJ ? h->rs_rx : drx, sJ);
+                if (rc) return rc;
+                if (sJ) {
+                    rc = unscale_jacobian_side(h, dd);
+                    if (rc) return rc;
+                }
+                GN_ROUTE(ENLSIP_GN_ROUTE_RESCALED);
+            }
+        } else if (flagged) {
+            // a batch: every nominated problem whose inputs are beyond the band goes to a one-problem handle of its own (which
+            // rescales in place as above); its outputs land in the caller's slots, the accessors are routed to it
+            for (long long k = 0; k < batch; ++k) {
+                if (!(h->h_state[k].status & fl)) continue;
+                int sJ = 0, sA = 0;
+                rc = extreme_shifts(h, m, n, t, dJ + k * strideJ, ldj, drx + k * m, dAt ? dAt + k * strideAt : nullptr, ldat,
+                                    dcx ? dcx + k * t : nullptr, &sJ, &sA);
+                if (rc) return rc;
+                if (!sJ && !sA) continue;
+                const size_t j = h->rescue_prob.size();
+                if (j >= 64) { h->err = "more than 64 problems of the batch need rescaling (magnitudes beyond 2^+-400): solve them separately"; return -18; }
+                if (j >= h->rescue.size()) {
+                    enlsip_gn_opts o{};
+                    o.device = h->device; o.flags = h->flags; o.panel_width = 0; o.tile_rows = h->tile_rows; o.stream = nullptr;
+                    enlsip_gn_handle r = nullptr;
+                    rc = enlsip_gn_create(&r, &o);
+                    if (rc) { h->err = "could not create a handle for a rescaled problem"; return rc; }
+                    r->is_rescue = true;
+                    r->pipeline = false;
+                    h->rescue.push_back(r);
+                }
+                enlsip_gn_handle r = h->rescue[j];
+                const unsigned long long route_here = gn_route_acc;
+                rc = solve_dev(r, 1, m, n, t, dJ + k * strideJ, ldj, strideJ, drx + k * m, dAt ? dAt + k * strideAt : nullptr, ldat, strideAt,
+                               dcx ? dcx + k * t : nullptr, eps_rank, dimA_ov, dimJ2_ov, dp ? dp + k * n : nullptr, db ? db + k * t : nullptr,
+                               dd ? dd + k * m : nullptr, nullptr, djA ? djA + k * t : nullptr, djL ? djL + k * P.kA : nullptr,
+                               djJ ? djJ + k * n : nullptr, nullptr);
+                gn_route_acc = route_here | r->route;
+                if (rc) { h->err = r->err; return rc; }
+                GN_HIP(hipSetDevice(h->device));
+                h->h_state[k] = r->h_state[0];
+                h->rescue_prob.push_back(k);
+            }
+        }
+        if (flagged) {       // the nomination bits are host-internal
+            for (long long k = 0; k < batch; ++k) h->h_state[k].status &= ~fl;
+            hipLaunchKernelGGL(k_clear_status_bits, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, s, h->state, fl, (int)batch);
+            GN_HIP(hipGetLastError());
+        }
     }
     if (hinfo)
         for (long long k = 0; k < batch; ++k) {
@@ -1061,6 +1393,7 @@ static int solve_dev(enlsip_gn_handle h, long long batch, long long m, long long
         (void)map;
     }
     h->factors_valid = true;
+    h->route = gn_route_acc;
     return 0;
 }
 
@@ -1114,18 +1447,24 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         const char* lk = getenv("ENLSIP_GN_LOOKAHEAD");      // 0: the pair sweep on one stream (A/B)
         if (lk && lk[0] == '0') h->lookahead = false;
         if (lk && lk[0] == '1') h->lookahead_forced = true;   // 1: for every paired sweep (tests)
+        const char* ld = getenv("ENLSIP_GN_LA_DEEP");        // 0: look-ahead with one chain stream (the round-4 schedule; A/B, tests)
+        if (ld && ld[0] == '0') h->la_deep = false;
         const char* fs = getenv("ENLSIP_GN_FUSE_SMALL");     // 0: J*Q1 and the one-tile panel factorisation as two launches (A/B)
         if (fs && fs[0] == '0') h->fuse_small = false;
         const char* fh = getenv("ENLSIP_GN_SB_FORM_HINTS");   // 0: every block of the blocked pivoted QR in all of its forms (A/B)
         if (fh && fh[0] == '0') h->sb_form_hints = false;
         const char* hy = getenv("ENLSIP_GN_QRCP_HYBRID");     // 0: more than 512 rows = one launch per pivot step to the end (A/B)
         if (hy && hy[0] == '0') h->qrcp_hybrid = false;
+#ifdef ENLSIP_GN_LAB       // laboratory build only (gn_device_utils.hpp): A/B and fault-location switches that no test of the suite uses
         const char* f4 = getenv("ENLSIP_GN_FACTOR_NW4");
         if (f4) h->factor_nw4 = atoi(f4);
         const char* dm = getenv("ENLSIP_GN_DEBUG_MAXPAN");
         if (dm) h->debug_maxpan = atoi(dm);
         const char* ds = getenv("ENLSIP_GN_DEBUG_STAGE");
         if (ds) h->debug_stage = atoi(ds);
+#endif
+        const char* rs = getenv("ENLSIP_GN_RESCALE");         // 0: no detection / rescaling of magnitudes beyond plain sums of squares (A/B, tests)
+        if (rs && rs[0] == '0') h->rescale_enabled = false;
         const char* pl = getenv("ENLSIP_GN_PIPELINE");       // 0: never split a batch over two streams
         if (pl && pl[0] == '0') h->pipeline = false;
         if (pl && pl[0] == '1') h->pipeline_forced = true;    // 1: split even the small uniform shapes (A/B)
@@ -1160,6 +1499,8 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);      // look-ahead sweep: an error return may have left work there
+    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
+    if (h->stream4) (void)hipStreamSynchronize(h->stream4);
     if (h->ws.p) (void)hipFree(h->ws.p);
     if (h->in_stage.p) (void)hipFree(h->in_stage.p);
     if (h->out_stage.p) (void)hipFree(h->out_stage.p);
@@ -1177,11 +1518,15 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->upd_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->oth_ev) (void)hipEventDestroy(e);
+    if (h->rs_buf.p) (void)hipFree(h->rs_buf.p);
+    for (enlsip_gn_handle r : h->rescue) (void)enlsip_gn_destroy(r);
     if (h->sub) (void)enlsip_gn_destroy(h->sub);
     if (h->child) (void)enlsip_gn_destroy(h->child);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->stream3) (void)hipStreamDestroy(h->stream3);
+    if (h->stream4) (void)hipStreamDestroy(h->stream4);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1302,6 +1647,27 @@ int enlsip_gn_get_update_stats(enlsip_gn_handle h, float* avg_ms, int64_t* launc
     return 0;
 }
 
+int enlsip_gn_get_route(enlsip_gn_handle h, uint64_t* mask) {
+    if (!h) return -1;
+    if (!mask) return -2;
+    *mask = (uint64_t)h->route;
+    return 0;
+}
+
+const char* enlsip_gn_route_name(int bit) {
+    static_assert(ENLSIP_GN_ROUTE_COUNT == 51, "one name per route bit");
+    static const char* const names[ENLSIP_GN_ROUTE_COUNT] = {
+        "constraint_wave32", "constraint_wave64", "constraint_lds_r1_256", "constraint_lds_r1_512", "constraint_lds_r2",
+        "constraint_lds_r4", "constraint_lds_r8", "constraint_lds_r16", "constraint_global", "constraint_reg4", "constraint_reg8", "constraint_dist",
+        "jq1_fused_small", "jq1_rows32", "jq1_rows2", "jq1_rows64", "jq1_v2_n128", "jq1_v2_n256", "jq1_v2_n384", "jq1_v2_n512",
+        "jq1_mfma", "jq1_plain", "sweep_plain", "sweep_pairs", "sweep_lookahead", "sweep_passenger", "sweep_tree",
+        "sweep_tile256", "sweep_tile512", "sweep_reflectors", "sweep_upper_input", "pivot_wave32", "pivot_wave64", "pivot_wave2",
+        "pivot_lds_r1_256", "pivot_lds_r1_512", "pivot_lds_r2", "pivot_lds_r4", "pivot_lds_r8", "pivot_lds_r16", "pivot_blocks",
+        "pivot_blocks_448", "pivot_blocks_512", "pivot_blocks_256", "pivot_blocks_128", "pivot_hybrid", "pivot_steps",
+        "pipeline_split", "chunked", "second_attempt", "rescaled"};
+    return (bit >= 0 && bit < ENLSIP_GN_ROUTE_COUNT) ? names[bit] : nullptr;
+}
+
 int enlsip_gn_get_launch_plan(enlsip_gn_handle h, int64_t* pipeline_split, int* panel_pairs, int64_t* tile_rows) {
     if (!h) return -1;
     if (!h->have_plan) { h->err = "no solve on this handle yet"; return -1; }
@@ -1374,6 +1740,7 @@ static int solve_launchable(enlsip_gn_handle h, int64_t batch, int64_t m, int64_
         if (rc0) return rc0;
         if (rc1) { h->err = c->err; return rc1; }
         h->split = b0;
+        h->route |= c->route | (1ull << ENLSIP_GN_ROUTE_PIPELINE_SPLIT);
         return 0;
     }
     return solve_dev(h, batch, m, n, t, dJ, ldj, strideJ, drx, dAt, ldat, strideAt, dcx, eps_rank, dimA_ov, dimJ2_ov, dp, db,
@@ -1392,6 +1759,7 @@ static int solve_chunked(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n
     const int64_t kA = std::min(n, t);
     const int64_t nchunks = (batch + GN_MAX_LAUNCH_BATCH - 1) / GN_MAX_LAUNCH_BATCH;
     const int64_t per = (batch + nchunks - 1) / nchunks;
+    unsigned long long route_all = nchunks > 1 ? (1ull << ENLSIP_GN_ROUTE_CHUNKED) : 0ull;
     for (int64_t c0 = 0; c0 < batch; c0 += per) {
         const int64_t nb = std::min(per, batch - c0);
         int rc = solve_launchable(h, nb, m, n, t, dJ + c0 * strideJ, ldj, strideJ, drx + c0 * m,
@@ -1401,6 +1769,8 @@ static int solve_chunked(enlsip_gn_handle h, int64_t batch, int64_t m, int64_t n
                                   djL ? djL + c0 * kA : nullptr, djJ ? djJ + c0 * n : nullptr, hinfo ? hinfo + c0 : nullptr);
         if (rc) return rc;
         h->chunk0 = c0;
+        route_all |= h->route;
+        h->route = route_all;
     }
     return 0;
 }
@@ -1522,10 +1892,39 @@ int enlsip_gn_factor_constraints(enlsip_gn_handle h, int64_t m, int64_t n, int64
     h->last_J = nullptr; h->last_rx = nullptr;
     h->last_cx = dcx; h->last_stride_cx = t;
     h->last_At = dAt; h->last_ldat = n; h->last_strideAt = (long long)n * t;
+    h->sc_eJ = 0; h->sc_eA = 0;
+    h->rescue_prob.clear();
     rc = run_constraint_stage(h, 1, m, n, t, dAt, n, (long long)n * t, dcx, eps_rank, -1);
     if (rc) return rc;
+    if (h->rescale_enabled && t > 0)
+        hipLaunchKernelGGL(k_extreme_flags, dim3(1), dim3(256), 0, s, h->state, (const double*)nullptr, 0LL, (const double*)h->FA, h->plan.sFA,
+                           h->plan.kA, 0, 1);
     GN_HIP(hipMemcpyAsync(h->h_state, h->state, sizeof(ProbState), hipMemcpyDeviceToHost, s));
     GN_HIP(hipStreamSynchronize(s));
+    if (h->h_state[0].status & (GN_FLAG_NONFINITE | GN_FLAG_TINY)) {
+        // A', cx beyond the range of plain sums of squares: the stage again on copies scaled by a power of two (gn_rescale.hpp)
+        int sJ = 0, sA = 0;
+        rc = extreme_shifts(h, m, n, t, nullptr, 0, nullptr, dAt, n, dcx, &sJ, &sA);
+        if (rc) return rc;
+        if (sA) {
+            const size_t nJ = (size_t)m * n, nA = (size_t)n * t;
+            rc = grow(h, h->rs_buf, (nJ + (size_t)m + nA + (size_t)t + 8) * 8);
+            if (rc) return rc;
+            h->rs_J = (double*)h->rs_buf.p; h->rs_rx = h->rs_J + nJ; h->rs_At = h->rs_rx + m; h->rs_cx = h->rs_At + nA;
+            hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)t), dim3(256), 0, s, h->rs_At,
+                               (long long)n, (const double*)dAt, (long long)n, (int)n, (int)t, sA);
+            hipLaunchKernelGGL(k_scale_copy, dim3(1, 1), dim3(256), 0, s, h->rs_cx, (long long)t, (const double*)dcx, (long long)t, (int)t, 1, sA);
+            h->sc_eA = sA;
+            rc = run_constraint_stage(h, 1, m, n, t, dAt, n, (long long)n * t, dcx, eps_rank, -1);
+            if (rc) return rc;
+            GN_HIP(hipMemcpyAsync(h->h_state, h->state, sizeof(ProbState), hipMemcpyDeviceToHost, s));
+            GN_HIP(hipStreamSynchronize(s));
+            h->route |= (1ull << ENLSIP_GN_ROUTE_RESCALED);
+        }
+        h->h_state[0].status &= ~(GN_FLAG_NONFINITE | GN_FLAG_TINY);
+        hipLaunchKernelGGL(k_clear_status_bits, dim3(1), dim3(256), 0, s, h->state, GN_FLAG_NONFINITE | GN_FLAG_TINY, 1);
+        GN_HIP(hipGetLastError());
+    }
     h->factors_valid = true;
     h->constraints_only = true;
     if (info) {

@@ -103,6 +103,8 @@ struct enlsip_gn_context {
     bool lookahead_forced = false;
     bool lookahead = true;              // ENLSIP_GN_LOOKAHEAD=0: chain-bound pair sweeps on one stream
     hipStream_t stream2 = nullptr;      // second stream of the look-ahead sweep (the bulk of a pair's far update)
+    hipStream_t stream3 = nullptr, stream4 = nullptr;   // deep look-ahead: the first panel's tree + the next pair's first-panel columns / its second-panel columns
+    bool la_deep = true;                // ENLSIP_GN_LA_DEEP=0: the round-4 schedule (one chain stream + the bulk stream)
     std::vector<hipEvent_t> la_events;
     bool fuse_small = true;             // ENLSIP_GN_FUSE_SMALL=0: two launches for J*Q1 + panel factorisation of one-tile problems
     int factor_nw4 = 0;                 // ENLSIP_GN_FACTOR_NW4 (A/B): 1 = level-0 tiles factored by 4 waves x 8 columns, 2 = tree nodes too
@@ -113,6 +115,18 @@ struct enlsip_gn_context {
     long long pipeline_min = 128;       // smallest batch that is split
     long long split = 0;                // problems [split, batch) of the last solve live on `child` (0: not split)
     hipEvent_t ev_fork = nullptr;
+    // Rescale path (gn_rescale.hpp): the resident problem of a one-problem solve whose inputs were beyond the range of plain sums
+    // of squares was solved on copies scaled by 2^sc_eJ (J, rx) / 2^sc_eA (A', cx), kept in rs_buf for the entry points that run the
+    // constraint stage again (re-solve, Newton); the resident factors are scaled back, i.e. they are those of the caller's data.
+    // In a batch such a problem is handed to a one-problem rescue handle of its own, to which the accessors are routed.
+    int sc_eJ = 0, sc_eA = 0;
+    gn::DevBuf rs_buf;
+    double *rs_J = nullptr, *rs_rx = nullptr, *rs_At = nullptr, *rs_cx = nullptr;
+    bool rescale_enabled = true;        // ENLSIP_GN_RESCALE=0: detection and rescaling off (A/B; tests)
+    bool is_rescue = false;
+    std::vector<enlsip_gn_context*> rescue;     // one-problem handles of rescaled problems of the last batch
+    std::vector<long long> rescue_prob;          // their problem indices (same length while the batch is resident)
+    unsigned long long route = 0;       // ENLSIP_GN_ROUTE_* bits of the last solve (enlsip_gn_get_route)
     long long chunk0 = 0;               // first problem (index in the caller's batch) of the resident chunk: batches above the launch limit run in chunks
     long long tsqr_n2 = -1;             // n2 of the last tsqr_local on this handle
     // communicator of enlsip_gn_solve_tsqr: an RCCL communicator (created here or handed in) or the caller's all-gather
@@ -122,6 +136,7 @@ struct enlsip_gn_context {
     void* tsqr_xctx = nullptr;
     int tsqr_ranks = 1, tsqr_rank = 0;
     bool tsqr_broken = false;           // enlsip_gn_tsqr_init_rccl failed: enlsip_gn_solve_tsqr refuses until a communicator is set again
+    int tsqr_tags_seen = -1;            // gathered messages of the last enlsip_gn_solve_tsqr whose header carried the rank of their slot
     int tsqr_transport = 0;             // what moved the triangles in the last enlsip_gn_solve_tsqr (ENLSIP_GN_TRANSPORT_*)
     gn::DevBuf xbuf;                    // send message + G received messages
     float tsqr_ms[3] = {};              // local / exchange / combine of the last enlsip_gn_solve_tsqr (profiling on)

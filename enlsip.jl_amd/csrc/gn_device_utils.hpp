@@ -3,9 +3,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/enlsip_gn.h"
+
 namespace gn {
 
 constexpr int WAVE = 64;
+
+// ENLSIP_GN_LAB (not set by build.sh): the laboratory build.  Only with it do the timing ablations (ENLSIP_V4_ABLATE,
+// ENLSIP_FACTOR_ABLATE: kernels whose RESULTS ARE WRONG by design), the phase-stamp macros (ENLSIP_V4_STAMPS,
+// ENLSIP_FACTOR_STAMPS, ENLSIP_SB_STEP_STAMPS, GN_PS_STAMPS) and the A/B run-time switches that no test of the suite uses
+// (ENLSIP_GN_FACTOR_NW4, ENLSIP_GN_DEBUG_MAXPAN, ENLSIP_GN_DEBUG_STAGE, ENLSIP_GN_JQ1_ROWS2) exist; the product build refuses the
+// macros and never reads those variables.  tests/microbench/*.hip and tests/probes/*.sh build with -DENLSIP_GN_LAB.
+#ifndef ENLSIP_GN_LAB
+#if (defined(ENLSIP_V4_ABLATE) && ENLSIP_V4_ABLATE != 0) || (defined(ENLSIP_FACTOR_ABLATE) && ENLSIP_FACTOR_ABLATE != 0) || \
+    defined(ENLSIP_V4_STAMPS) || defined(ENLSIP_FACTOR_STAMPS) || defined(ENLSIP_SB_STEP_STAMPS) || defined(GN_PS_STAMPS)
+#error "timing ablations and phase stamps are laboratory code: build with -DENLSIP_GN_LAB"
+#endif
+#endif
+
+// Host side: kernel-selection record of the solve that runs on this thread (include/enlsip_gn.h: ENLSIP_GN_ROUTE_*); the launch
+// helpers OR their bit in, solve_dev folds it into the handle.  A pipelined solve runs its second half on a thread of its own.
+inline thread_local unsigned long long gn_route_acc = 0;
+#define GN_ROUTE(bit) (::gn::gn_route_acc |= (1ull << (bit)))
 
 // Per-problem device record: written by the constraint stage, read by every later kernel, so no
 // host round trip is needed in the middle of a solve.
@@ -357,13 +376,24 @@ __device__ __forceinline__ NormDown norm_downdate(const double o1, const double 
 
 // pseudo_rank (src/enlsip_functions.jl:17-31), diag accessed through a functor; serial, call
 // from one lane.
+// eps_abs: the threshold of the FIRST test, which is absolute.  It equals eps_rank except when the factor at hand belongs to
+// inputs that the host scaled by a power of two (magnitudes beyond the range of plain sums of squares, enlsip_gn.hip
+// "rescale"): the diagonal is then 2^shift times the true one and the test compares it with 2^shift eps_rank — the decision
+// LAPACK's scaled norms would lead to on the unscaled data.  The second test is relative and needs nothing.
+__device__ __forceinline__ double pseudo_rank_abs_threshold(double eps_rank, int abs_shift) {
+    return abs_shift ? __builtin_ldexp(eps_rank, abs_shift) : eps_rank;
+}
 template <class DiagFn>
-__device__ inline int pseudo_rank_serial(int len, double eps_rank, DiagFn diag) {
-    if (len == 0 || fabs(diag(0)) < eps_rank) return 0;
+__device__ inline int pseudo_rank_serial(int len, double eps_rank, DiagFn diag, double eps_abs) {
+    if (len == 0 || fabs(diag(0)) < eps_abs) return 0;
     const double tol = fabs(diag(0)) * sqrt((double)len) * eps_rank;
     int r = 1;
     while (r < len && fabs(diag(r - 1)) > tol) ++r;
     return r - ((r == len && fabs(diag(r - 1)) > tol) ? 0 : 1);
+}
+template <class DiagFn>
+__device__ inline int pseudo_rank_serial(int len, double eps_rank, DiagFn diag) {
+    return pseudo_rank_serial(len, eps_rank, diag, eps_rank);
 }
 
 }  // namespace gn

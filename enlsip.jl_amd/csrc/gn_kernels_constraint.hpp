@@ -18,6 +18,7 @@ constexpr int CMAT_DOUBLES = 8192; // LDS matrix area (64 KB)
 struct ConstraintArgs {
     int n, t, kA, m;
     double eps_rank;
+    int abs_shift;       // 0, or the power of two At and cx were scaled by (pseudo_rank_abs_threshold)
     int dimA_override;   // -1 = rankA
     int code_override;   // 0 = derive from rankA; +1 / -1 force (resolve path)
     int prob0;           // problem index offset
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(NTH) void k_constraint(ConstraintArgs a) {
     for (int i = tid; i < kA; i += nt) ybuf[i] = FA[i + (size_t)i * n];      // diagonal -> LDS in parallel (see k_pivot_solve)
     __syncthreads();
     if (tid == 0) {
-        int rk = pseudo_rank_serial(kA, a.eps_rank, [&](int i) { return ybuf[i]; });
+        int rk = pseudo_rank_serial(kA, a.eps_rank, [&](int i) { return ybuf[i]; }, pseudo_rank_abs_threshold(a.eps_rank, a.abs_shift));
         sh_i[1] = rk;
     }
     __syncthreads();

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_CS_OCC) ? ENLSIP_CS_OCC : (
         const int jcols = (kA <= Q1R_MAXK) ? kA : KBLK;
         for (int jc = 0; jc < jcols; ++jc) T[ln + jc * KBLK] = (jc < kA && ln <= jc) ? Tl[ln + 64 * jc] : 0.0;
     }
-    const int rankA = wave_pseudo_rank(dg, kA, a.eps_rank, ln);
+    const int rankA = wave_pseudo_rank(dg, kA, a.eps_rank, ln, pseudo_rank_abs_threshold(a.eps_rank, a.abs_shift));
     int code = (rankA == t) ? 1 : -1;
     if (a.code_override != 0) code = a.code_override;
     int dimA = (a.dimA_override >= 0) ? a.dimA_override : rankA;
@@ -160,8 +160,8 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_CS_OCC) ? ENLSIP_CS_OCC : (
 inline bool launch_constraint_small(int batch, hipStream_t s, const ConstraintArgs& a) {
     if (a.n > 64 || a.t > 63 || a.fa_done) return false;
     const size_t lds = constraint_small_lds_bytes(a.kA);
-    if (a.n <= 32 && a.t <= 32) hipLaunchKernelGGL(k_constraint_small<32>, dim3(batch), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL(k_constraint_small<64>, dim3(batch), dim3(64), lds, s, a);
+    if (a.n <= 32 && a.t <= 32) { GN_ROUTE(ENLSIP_GN_ROUTE_CONSTRAINT_WAVE32); hipLaunchKernelGGL(k_constraint_small<32>, dim3(batch), dim3(64), lds, s, a); }
+    else { GN_ROUTE(ENLSIP_GN_ROUTE_CONSTRAINT_WAVE64); hipLaunchKernelGGL(k_constraint_small<64>, dim3(batch), dim3(64), lds, s, a); }
     return true;
 }
 

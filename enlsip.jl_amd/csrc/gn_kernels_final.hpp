@@ -16,6 +16,7 @@ namespace gn {
 struct FinalArgs {
     int m, n, t, kA, ldw, ldr;
     double eps_rank;
+    int abs_shift;        // 0, or the power of two J and rx were scaled by (pseudo_rank_abs_threshold)
     int dimJ2_override;   // -1 = rankJ2
     int refactor;         // 1: extract R0 and factor it here; 2: Rt already factored (distributed path);
                           // 0: reuse resident Rt (resolve path)
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(NTH) void k_pivot_solve(FinalArgs a) {
         for (int i = tid; i < kp; i += nt) pbuf[i] = Rt[i + (size_t)i * ldr];
         __syncthreads();
         if (tid == 0) {
-            sh_i[1] = pseudo_rank_serial(kp, a.eps_rank, [&](int i) { return pbuf[i]; });
+            sh_i[1] = pseudo_rank_serial(kp, a.eps_rank, [&](int i) { return pbuf[i]; }, pseudo_rank_abs_threshold(a.eps_rank, a.abs_shift));
         }
         __syncthreads();
         rankJ2 = sh_i[1];

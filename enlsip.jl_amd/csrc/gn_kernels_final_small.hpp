@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_PS_OCC) ? ENLSIP_PS_OCC : (
     wave_mem_sync();
     const int lp = (ln <= n2) ? lpos[ln] : 0;
     wave_qrcp_store_upper(q, ln, lp, n2 + 1, Rt, ldr);
-    const int rankJ2 = wave_pseudo_rank(dg, kp, a.eps_rank, ln);
+    const int rankJ2 = wave_pseudo_rank(dg, kp, a.eps_rank, ln, pseudo_rank_abs_threshold(a.eps_rank, a.abs_shift));
     int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
     dimJ2 = dimJ2 < kp ? dimJ2 : kp;      // as k_pivot_solve: never past the factor
     GN_PS_STAMP(3);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) 
             const double tol = d0 * sqrt((double)(kp > 0 ? kp : 1)) * a.eps_rank;
             const bool fail = (lh < kp) && !(fabs(dgh[lh < kp ? lh : 0]) > tol);
             const unsigned mh = (unsigned)(__ballot(fail) >> hb);
-            if (kp > 0 && !(d0 < a.eps_rank)) rankJ2 = mh ? (int)__builtin_ctz(mh) : kp;
+            if (kp > 0 && !(d0 < pseudo_rank_abs_threshold(a.eps_rank, a.abs_shift))) rankJ2 = mh ? (int)__builtin_ctz(mh) : kp;
         }
         int dimJ2 = (a.dimJ2_override >= 0) ? a.dimJ2_override : rankJ2;
         dimJ2 = dimJ2 < kp ? dimJ2 : kp;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64, 3) void k_pivot_small2(FinalArgs a, int nprob) 
         int rankJ2 = 0;
         if (kpu > 0) {
             const double d0 = fabs(dgh[0]);
-            if (!(d0 < a.eps_rank)) {
+            if (!(d0 < pseudo_rank_abs_threshold(a.eps_rank, a.abs_shift))) {
                 const double tol = d0 * sqrt((double)kpu) * a.eps_rank;
                 const bool fail = (ln < kpu) && !(fabs(dgh[ln < kpu ? ln : 0]) > tol);
                 const unsigned long long mk = __ballot(fail);
@@ -442,12 +442,13 @@ inline bool launch_pivot_small(int kp_launch, int n2_launch, int batch, hipStrea
     a.matd = (a.matd + 1) / 2 * 2;
     if (kp_launch <= 32 && n2_launch + 1 <= 32 && batch > 1) {      // two problems per wave
         a.matd = kp_launch > 0 ? kp_launch : 1;
+        GN_ROUTE(ENLSIP_GN_ROUTE_PIVOT_WAVE2);
         hipLaunchKernelGGL(k_pivot_small2, dim3((batch + 1) / 2), dim3(64), final_small2_lds_bytes(a.matd, a.nv), s, a, batch);
         return true;
     }
     const size_t lds = final_small_lds_bytes(0, a.nv) + (size_t)a.matd * 8;
-    if (kp_launch <= 32) hipLaunchKernelGGL(k_pivot_small<32>, dim3(batch), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL(k_pivot_small<64>, dim3(batch), dim3(64), lds, s, a);
+    if (kp_launch <= 32) { GN_ROUTE(ENLSIP_GN_ROUTE_PIVOT_WAVE32); hipLaunchKernelGGL(k_pivot_small<32>, dim3(batch), dim3(64), lds, s, a); }
+    else { GN_ROUTE(ENLSIP_GN_ROUTE_PIVOT_WAVE64); hipLaunchKernelGGL(k_pivot_small<64>, dim3(batch), dim3(64), lds, s, a); }
     return true;
 }
 

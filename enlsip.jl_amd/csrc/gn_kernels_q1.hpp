@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void k_jq1(JQ1Args a) {
 }
 
 inline void launch_jq1(const JQ1Args& a, int batch, hipStream_t s) {
+    GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_PLAIN);
     const size_t lds16 = jq1_lds_doubles(a.n, 16) * 8;
     if (lds16 <= 160 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_jq1<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);

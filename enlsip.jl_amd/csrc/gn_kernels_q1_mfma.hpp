@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_jq1_mfma(JQ1Args a) {
 }
 
 inline void launch_jq1_mfma(const JQ1Args& a, int batch, hipStream_t s) {
+    GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_MFMA);
     hipLaunchKernelGGL(k_jq1_mfma, dim3((a.ldw + QM_RB - 1) / QM_RB, batch), dim3(256), 0, s, a);
 }
 

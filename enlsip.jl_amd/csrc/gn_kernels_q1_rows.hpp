@@ -133,10 +133,14 @@ __global__ __launch_bounds__(256, 3) void k_jq1_rows2(JQ1Args a) {
 inline bool launch_jq1_rows(const JQ1Args& a, int batch, hipStream_t s) {
     if (a.n > 64 || a.kA > Q1R_MAXK) return false;
     const dim3 grid((a.ldw + 255) / 256, batch);
+#ifdef ENLSIP_GN_LAB
     static const bool two = !(getenv("ENLSIP_GN_JQ1_ROWS2") && getenv("ENLSIP_GN_JQ1_ROWS2")[0] == '0');      // A/B switch
-    if (a.n <= 32) hipLaunchKernelGGL(k_jq1_rows<32>, grid, dim3(256), 0, s, a);
-    else if (two && a.ldj < (1 << 23) && a.ldw < (1 << 23)) hipLaunchKernelGGL(k_jq1_rows2<0>, dim3((a.ldw + 127) / 128, batch), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_jq1_rows<64>, grid, dim3(256), 0, s, a);
+#else
+    constexpr bool two = true;
+#endif
+    if (a.n <= 32) { GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_ROWS32); hipLaunchKernelGGL(k_jq1_rows<32>, grid, dim3(256), 0, s, a); }
+    else if (two && a.ldj < (1 << 23) && a.ldw < (1 << 23)) { GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_ROWS2); hipLaunchKernelGGL(k_jq1_rows2<0>, dim3((a.ldw + 127) / 128, batch), dim3(256), 0, s, a); }
+    else { GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_ROWS64); hipLaunchKernelGGL(k_jq1_rows<64>, grid, dim3(256), 0, s, a); }
     return true;
 }
 

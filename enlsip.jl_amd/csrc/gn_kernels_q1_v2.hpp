@@ -364,10 +364,10 @@ inline bool launch_jq1_v2(const JQ1Args& a, int batch, hipStream_t s) {
     dim3 grid(a.m / 32, batch);
     dim3 blk(256);
     switch (a.n / 128) {
-        case 1: hipLaunchKernelGGL((k_jq1_v2<2, 4, 2>), grid, blk, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_jq1_v2<4, 4, 2>), grid, blk, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((k_jq1_v2<6, 4, 2>), grid, blk, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_jq1_v2<8, 4, 2>), grid, blk, 0, s, a); break;
+        case 1: GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_V2_N128); hipLaunchKernelGGL((k_jq1_v2<2, 4, 2>), grid, blk, 0, s, a); break;
+        case 2: GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_V2_N256); hipLaunchKernelGGL((k_jq1_v2<4, 4, 2>), grid, blk, 0, s, a); break;
+        case 3: GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_V2_N384); hipLaunchKernelGGL((k_jq1_v2<6, 4, 2>), grid, blk, 0, s, a); break;
+        default: GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_V2_N512); hipLaunchKernelGGL((k_jq1_v2<8, 4, 2>), grid, blk, 0, s, a); break;
     }
     return true;
 }

@@ -147,6 +147,7 @@ inline bool small_fused_applies(long long m, long long n, int kA, int n2_launch)
     return m <= 256 && n <= 32 && kA <= Q1R_MAXK && n2_launch >= 1 && n2_launch < PB && m >= n2_launch;
 }
 inline void launch_jq1_factor_small(const JQ1Args& q, const CaqrArgs& a, int batch, hipStream_t s) {
+    GN_ROUTE(ENLSIP_GN_ROUTE_JQ1_FUSED_SMALL);
     hipLaunchKernelGGL(k_jq1_factor_small<32>, dim3(1, batch), dim3(256), 0, s, q, a);
 }
 

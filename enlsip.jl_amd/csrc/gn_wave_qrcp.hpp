@@ -209,10 +209,10 @@ __device__ __forceinline__ void wave_qrcp_store_upper(const WaveQrcp& q, const i
 }
 
 // pseudo_rank (src/enlsip_functions.jl:17-31) of the diagonal in LDS (len <= 64), evaluated by the whole wave.
-__device__ __forceinline__ int wave_pseudo_rank(const double* dg, const int len, const double eps_rank, const int ln) {
+__device__ __forceinline__ int wave_pseudo_rank(const double* dg, const int len, const double eps_rank, const int ln, const double eps_abs) {
     if (len <= 0) return 0;
     const double d0 = fabs(dg[0]);
-    if (d0 < eps_rank) return 0;
+    if (d0 < eps_abs) return 0;
     const double tol = d0 * sqrt((double)len) * eps_rank;
     const bool fail = (ln < len) && !(fabs(dg[ln < len ? ln : 0]) > tol);
     const unsigned long long mk = __ballot(fail);

@@ -121,6 +121,34 @@ function Base.:*(Q::DeviceQ, v::AbstractVector{Float64})
     return out
 end
 
+# M * F.Q and M * F.Q' — what the reference's consumers write as `J * F_A.Q` (src/enlsip_functions.jl:384, :526, :1249), so that
+# those lines run UNMODIFIED on a DeviceQR.  `F_A.Q` applied from the right to a matrix with as many rows as the J of the last
+# solve is one launch of the library's J*Q1 kernel on the resident reflectors (enlsip_gn_matrix_times_QA: M is staged, nothing
+# about it needs to be resident); every other combination (F_L11 / F_J2, adjoints, other row counts) falls back to one
+# `Q' * row` per row of M — correct for any M, slow for tall ones, and not on any path the reference takes.
+function Base.:*(M::AbstractMatrix{Float64}, Q::DeviceQ)
+    F = Q.F
+    h = getfield(F, :h)
+    rows, cols = size(M)
+    cols == getfield(F, :rows) || throw(DimensionMismatch("matrix has $cols columns, Q acts on vectors of length $(getfield(F, :rows))"))
+    if getfield(F, :which) == FACTOR_A && !Q.adj
+        Md = Matrix{Float64}(M)
+        out = zeros(Float64, rows, cols)
+        rc = GC.@preserve Md out ccall((:enlsip_gn_matrix_times_QA, LIB), Cint,
+                                       (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64),
+                                       h.ptr, 0, rows, Md, max(rows, 1), out, max(rows, 1))
+        rc == 0 && return out
+        rc == -3 || check(h, rc)         # -3: rows differ from the resident plan's m — generic path below
+    end
+    # (M Q)' = Q' M'  and  (M Q')' = Q M': one vector application per row of M
+    out = Matrix{Float64}(undef, rows, cols)
+    Qt = DeviceQ(F, !Q.adj)
+    for i in 1:rows
+        out[i, :] = Qt * Vector{Float64}(M[i, :])
+    end
+    return out
+end
+
 # J * F_A.Q  (src/enlsip_functions.jl:219, :526, :1249): served from the device instead of a second dormqr
 function jq1(h::Handle, m::Integer, n::Integer)
     out = zeros(Float64, m, n)
@@ -282,6 +310,20 @@ function jacobian_times_hip(h::Handle, p::Vector{Float64}, m::Integer, t::Intege
     GC.@preserve p Jp Ap check(h, ccall((:enlsip_gn_jacobian_times, LIB), Cint,
         (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h.ptr, 0, p, Jp, t > 0 ? pointer(Ap) : Ptr{Float64}(C_NULL)))
     return Jp, Ap
+end
+
+"""    full_constraints_times_hip(h, A, p) -> A * p
+
+The product of the line-search set-up with the FULL constraint Jacobian, inactive rows included (`Ap = A * p`,
+src/enlsip_functions.jl:2227), on the device: `A` (l x n) is staged, nothing about it has to be resident.
+"""
+function full_constraints_times_hip(h::Handle, A::Matrix{Float64}, p::Vector{Float64})
+    l, n = size(A)
+    Ap = zeros(Float64, l)
+    l == 0 && return Ap
+    GC.@preserve A p Ap check(h, ccall((:enlsip_gn_full_constraints_times, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}), h.ptr, l, n, A, l, p, Ap))
+    return Ap
 end
 
 """    diagR(F::DeviceQR) -> diag(F.R) without moving the triangle (what `pseudo_rank(diag(F.R), ε)` needs, :768, :224)"""

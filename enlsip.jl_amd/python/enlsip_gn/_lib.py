@@ -84,6 +84,7 @@ PROTOTYPES = {
                                        C.c_double, C.c_void_p, C.c_void_p, _dp, C.POINTER(Info), C.c_void_p]),
     "enlsip_gn_tsqr_get_stage_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "enlsip_gn_tsqr_get_transport": (C.c_int, [_h, C.POINTER(C.c_int)]),
+    "enlsip_gn_tsqr_get_exchange": (C.c_int, [_h, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "enlsip_gn_set_profiling": (C.c_int, [_h, C.c_int]),
     "enlsip_gn_get_stage_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "enlsip_gn_get_update_stats": (C.c_int, [_h, C.POINTER(C.c_float), _ip, _dp]),
@@ -92,6 +93,10 @@ PROTOTYPES = {
     "enlsip_gn_get_update_totals": (C.c_int, [_h, C.POINTER(C.c_float), C.POINTER(C.c_float), _ip, _dp]),
     "enlsip_gn_measure_stream": (C.c_int, [_h, C.c_int64, C.c_int, _dp]),
     "enlsip_gn_debug_copy_W": (C.c_int, [_h, C.c_int64, _dp, _ip, C.c_int64]),
+    "enlsip_gn_full_constraints_times": (C.c_int, [_h, _i64, _i64, C.c_void_p, _i64, C.c_void_p, C.c_void_p]),
+    "enlsip_gn_matrix_times_QA": (C.c_int, [_h, _i64, _i64, C.c_void_p, _i64, C.c_void_p, _i64]),
+    "enlsip_gn_get_route": (C.c_int, [_h, C.POINTER(C.c_uint64)]),
+    "enlsip_gn_route_name": (C.c_char_p, [C.c_int]),
 }
 
 _lib = None

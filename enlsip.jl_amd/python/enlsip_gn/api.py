@@ -25,6 +25,18 @@ class GNError(RuntimeError):
     pass
 
 
+def route_names(lib=None) -> list:
+    """Every route bit the library knows, in bit order (enlsip_gn_route_name)."""
+    lib = lib or L.load()
+    names, bit = [], 0
+    while True:
+        nm = lib.enlsip_gn_route_name(bit)
+        if nm is None:
+            return names
+        names.append(nm.decode())
+        bit += 1
+
+
 def _fptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -232,6 +244,24 @@ class GNSolver:
         self._chk(self._lib.enlsip_gn_jacobian_times(self._h, prob, _fptr(pv), _fptr(Jp), _fptr(Ap) if t else None))
         return Jp, Ap
 
+    def full_constraints_times(self, A: np.ndarray, p: np.ndarray) -> np.ndarray:
+        """A p with the FULL constraint Jacobian (l x n), src/enlsip_functions.jl:2227."""
+        Af = np.asfortranarray(A, dtype=np.float64)
+        l, n = Af.shape
+        pv = np.ascontiguousarray(p, dtype=np.float64)
+        Ap = np.zeros(l)
+        if l:
+            self._chk(self._lib.enlsip_gn_full_constraints_times(self._h, l, n, _fptr(Af), l, _fptr(pv), _fptr(Ap)))
+        return Ap
+
+    def matrix_times_QA(self, M: np.ndarray, prob: int = 0) -> np.ndarray:
+        """M * F_A.Q for a host matrix with the row count of the last solve (`J * F_A.Q`, src/enlsip_functions.jl:526, :1249)."""
+        Mf = np.asfortranarray(M, dtype=np.float64)
+        rows, n = Mf.shape
+        out = np.zeros((rows, n), order="F")
+        self._chk(self._lib.enlsip_gn_matrix_times_QA(self._h, prob, rows, _fptr(Mf), max(rows, 1), _fptr(out), max(rows, 1)))
+        return out
+
     def first_lagrange(self, t: int, grad_fx: Optional[np.ndarray] = None, diag_scale: Optional[np.ndarray] = None,
                        eps_rank: float = SQRT_EPS, prob: int = 0):
         """first_lagrange_mult_estimate!: returns (lambda, grad_res)."""
@@ -291,6 +321,12 @@ class GNSolver:
         sp, pr, tr = C.c_int64(), C.c_int(), C.c_int64()
         self._chk(self._lib.enlsip_gn_get_launch_plan(self._h, C.byref(sp), C.byref(pr), C.byref(tr)))
         return int(sp.value), bool(pr.value), int(tr.value)
+
+    def route(self) -> set:
+        """Names of the kernel-selection branches the last solve took (enlsip_gn_get_route; include/enlsip_gn.h ENLSIP_GN_ROUTE_*)."""
+        mask = C.c_uint64(0)
+        self._chk(self._lib.enlsip_gn_get_route(self._h, C.byref(mask)))
+        return {name for bit, name in enumerate(route_names(self._lib)) if (mask.value >> bit) & 1}
 
     def pipeline_split(self) -> int:
         return self.launch_plan()[0]

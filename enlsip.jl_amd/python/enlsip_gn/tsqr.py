@@ -200,6 +200,14 @@ def tsqr_transport(solver: GNSolver) -> str:
     return TRANSPORT_NAMES.get(int(code.value), str(code.value))
 
 
+def tsqr_exchange(solver: GNSolver) -> dict:
+    """Transport, rank count and rank tags seen in the handle's last ``enlsip_gn_solve_tsqr`` (enlsip_gn_tsqr_get_exchange):
+    ``rank_tags_seen == ranks`` means one message from each distinct rank arrived in its slot."""
+    tr, rk, seen = C.c_int(-1), C.c_int(0), C.c_int(-1)
+    solver._chk(solver._lib.enlsip_gn_tsqr_get_exchange(solver._h, C.byref(tr), C.byref(rk), C.byref(seen)))
+    return {"transport": TRANSPORT_NAMES.get(int(tr.value), str(tr.value)), "ranks": int(rk.value), "rank_tags_seen": int(seen.value)}
+
+
 def tsqr_stage_ms(solver: GNSolver):
     arr = (C.c_float * 3)()
     solver._chk(solver._lib.enlsip_gn_tsqr_get_stage_ms(solver._h, arr))

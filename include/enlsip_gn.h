@@ -188,9 +188,21 @@ int enlsip_gn_resolve(enlsip_gn_handle h, int64_t prob, int64_t dimA, int64_t di
  * enlsip_gn_jacobian_times    Jp = J * p (m) and Ap = C.A * p (t, active rows), the products the line search sets up
  *                             with (src/enlsip_functions.jl:2226-2229: `Jp = J * p`, `active_Ap = (active_constraint.A) * p`),
  *                             on the J and A' of the last solve; either output may be NULL.  (The product with the FULL
- *                             constraint Jacobian, :2227, involves rows the library never sees and stays on the host.)
+ *                             constraint Jacobian, :2227: enlsip_gn_full_constraints_times.)
+ * enlsip_gn_full_constraints_times   Ap = A * p with the FULL constraint Jacobian A (l x n, column-major, host; inactive rows
+ *                             included): the other product of src/enlsip_functions.jl:2227 (`Ap = A * p`).  A is staged through
+ *                             PCIe for one gemv — offered so that the whole line-search set-up can stay behind the ABI; a host
+ *                             BLAS call is the faster choice for small l.  Needs no resident factors.
+ * enlsip_gn_matrix_times_QA   out = M * F_A.Q for a HOST matrix M with the row count m of the last solve (rows x n, ldm >= rows):
+ *                             what the reference writes as `J * F_A.Q` (src/enlsip_functions.jl:384, :526, :1249) for ANY such
+ *                             matrix — one launch of the J*Q1 kernel on the resident reflectors; -3 when rows != m.  The Julia
+ *                             glue's `Base.:*(::AbstractMatrix, ::DeviceQ)` rests on it.
  */
 int enlsip_gn_gradient(enlsip_gn_handle h, int64_t prob, double* grad);
+int enlsip_gn_full_constraints_times(enlsip_gn_handle h, int64_t l, int64_t n, const double* A, int64_t lda, const double* p,
+                                     double* Ap);
+int enlsip_gn_matrix_times_QA(enlsip_gn_handle h, int64_t prob, int64_t rows, const double* M, int64_t ldm, double* out,
+                              int64_t ldo);
 int enlsip_gn_jacobian_times(enlsip_gn_handle h, int64_t prob, const double* p, double* Jp, double* Ap);
 int enlsip_gn_first_lagrange(enlsip_gn_handle h, int64_t prob, const double* grad_fx, const double* diag_scale,
                              double eps_rank, double* lambda, double* grad_res);
@@ -282,6 +294,11 @@ enum {
     ENLSIP_GN_TRANSPORT_CALLBACK = 2  /* the caller's all-gather (enlsip_gn_tsqr_set_exchange) */
 };
 int enlsip_gn_tsqr_get_transport(enlsip_gn_handle h, int* transport);
+/* The same with the evidence that the collective really spanned the communicator: *ranks = the handle's rank count, and
+ * *rank_tags_seen = how many of the gathered messages carried, in their header, the rank their slot belongs to AND the same rank
+ * count (every message is tagged by its sender; -1: nothing was gathered, n2 = 0).  transport == RCCL and rank_tags_seen == ranks
+ * on every rank is "RCCL moved one message from each of N distinct ranks" (bench.py --config C4 prints and asserts it). */
+int enlsip_gn_tsqr_get_exchange(enlsip_gn_handle h, int* transport, int* ranks, int* rank_tags_seen);
 
 /* ---- instrumentation: HIP-event time (ms) of the stages of the last solve ------------------ */
 enum {
@@ -322,6 +339,68 @@ int enlsip_gn_get_update_totals(enlsip_gn_handle h, float* far_ms, float* other_
 /* GB/s (read + write) of an in-place non-temporal read-modify-write stream over `bytes` of the handle's scratch memory with the
  * trailing update's access shape, HIP events around `reps` passes: the same-box ceiling of an in-place update (bench.py) */
 int enlsip_gn_measure_stream(enlsip_gn_handle h, int64_t bytes, int reps, double* gbytes_per_s);
+/* Which kernel-selection branches of the host code the last solve on this handle took: one bit per branch (and per template
+ * instantiation a branch chooses between), ORed over both pipeline halves, every chunk and both attempts of a solve.  Every
+ * place in the library that picks a kernel from the shape sets a bit; tests/test_dispatch_grid.py derives a stratified shape
+ * list from the same conditions and asserts that every bit is hit by a case that is compared against the oracle — a new fast
+ * path gets a bit here and cannot ship without such a case.  enlsip_gn_route_name(bit) = its name, NULL past the last bit. */
+enum {
+    ENLSIP_GN_ROUTE_CONSTRAINT_WAVE32 = 0,   /* k_constraint_small<32>: n, t <= 32                                     */
+    ENLSIP_GN_ROUTE_CONSTRAINT_WAVE64,       /* k_constraint_small<64>: n <= 64, t <= 63                               */
+    ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R1_256,   /* k_constraint, matrices in LDS, rows <= 32                              */
+    ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R1_512,   /* rows <= 64                                                             */
+    ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R2,       /* rows <= 128                                                            */
+    ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R4,       /* rows <= 256                                                            */
+    ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R8,       /* rows <= 512                                                            */
+    ENLSIP_GN_ROUTE_CONSTRAINT_LDS_R16,      /* rows <= 1024                                                           */
+    ENLSIP_GN_ROUTE_CONSTRAINT_GLOBAL,       /* k_constraint factoring in global memory (beyond the LDS area, n > 512) */
+    ENLSIP_GN_ROUTE_CONSTRAINT_REG4,         /* F_A by k_geqp3_reg<4> (n <= 256, beyond the LDS area)                  */
+    ENLSIP_GN_ROUTE_CONSTRAINT_REG8,         /* F_A by k_geqp3_reg<8> (n <= 512)                                       */
+    ENLSIP_GN_ROUTE_CONSTRAINT_DIST,         /* more than 64 constraints beyond the LDS area: launch-per-step QR       */
+    ENLSIP_GN_ROUTE_JQ1_FUSED_SMALL,         /* k_jq1_factor_small: J*Q1 + the one narrow panel in one launch          */
+    ENLSIP_GN_ROUTE_JQ1_ROWS32,              /* k_jq1_rows<32>: a lane per row, n <= 32                                */
+    ENLSIP_GN_ROUTE_JQ1_ROWS2,               /* k_jq1_rows2: two lanes per row, 32 < n <= 64                           */
+    ENLSIP_GN_ROUTE_JQ1_ROWS64,              /* k_jq1_rows<64> (leading dimensions beyond 2^23)                        */
+    ENLSIP_GN_ROUTE_JQ1_V2_N128,             /* k_jq1_v2<2,4,2>: kA = 64, n = 128, m multiple of 32                    */
+    ENLSIP_GN_ROUTE_JQ1_V2_N256,
+    ENLSIP_GN_ROUTE_JQ1_V2_N384,
+    ENLSIP_GN_ROUTE_JQ1_V2_N512,
+    ENLSIP_GN_ROUTE_JQ1_MFMA,                /* k_jq1_mfma: every other shape                                          */
+    ENLSIP_GN_ROUTE_JQ1_PLAIN,               /* k_jq1 (ENLSIP_GN_UPDATE_REFLECTORS; also behind get_JQ1 / Newton)      */
+    ENLSIP_GN_ROUTE_SWEEP_PLAIN,             /* CAQR: one panel per pass over the trailing columns                     */
+    ENLSIP_GN_ROUTE_SWEEP_PAIRS,             /* two panels per pass over the far columns                               */
+    ENLSIP_GN_ROUTE_SWEEP_LOOKAHEAD,         /* a pair's far update split over two streams                             */
+    ENLSIP_GN_ROUTE_SWEEP_PASSENGER,         /* last narrow panel: d rides through the factor kernel                   */
+    ENLSIP_GN_ROUTE_SWEEP_TREE,              /* more than one tile: tree levels                                        */
+    ENLSIP_GN_ROUTE_SWEEP_TILE256,           /* 256-row tiles (m <= 256 or opts.tile_rows = 256)                       */
+    ENLSIP_GN_ROUTE_SWEEP_TILE512,
+    ENLSIP_GN_ROUTE_SWEEP_REFLECTORS,        /* trailing update reflector by reflector (ENLSIP_GN_UPDATE_REFLECTORS)   */
+    ENLSIP_GN_ROUTE_SWEEP_UPPER_INPUT,       /* J already upper triangular (TSQR combine of one shard): no sweep       */
+    ENLSIP_GN_ROUTE_PIVOT_WAVE32,            /* k_pivot_small<32>: kp <= 32, n2 + 1 <= 64, one problem                 */
+    ENLSIP_GN_ROUTE_PIVOT_WAVE64,            /* k_pivot_small<64>: kp <= 64, n2 + 1 <= 64                              */
+    ENLSIP_GN_ROUTE_PIVOT_WAVE2,             /* k_pivot_small2: two problems per wave, kp <= 32, n2 + 1 <= 32, batch   */
+    ENLSIP_GN_ROUTE_PIVOT_LDS_R1_256,        /* k_pivot_solve (pivoted QR of R0 in LDS, or only the solves behind the  */
+    ENLSIP_GN_ROUTE_PIVOT_LDS_R1_512,        /*                blocked form), by rows min(m, n): <= 32, 64, 128, ...   */
+    ENLSIP_GN_ROUTE_PIVOT_LDS_R2,
+    ENLSIP_GN_ROUTE_PIVOT_LDS_R4,
+    ENLSIP_GN_ROUTE_PIVOT_LDS_R8,
+    ENLSIP_GN_ROUTE_PIVOT_LDS_R16,
+    ENLSIP_GN_ROUTE_PIVOT_BLOCKS,            /* run_qrcp_block: register blocks (R0 beyond the LDS area, kp <= 512)    */
+    ENLSIP_GN_ROUTE_PIVOT_BLOCKS_448,        /*   forms of the block kernel that were launched: 448 rows               */
+    ENLSIP_GN_ROUTE_PIVOT_BLOCKS_512,
+    ENLSIP_GN_ROUTE_PIVOT_BLOCKS_256,
+    ENLSIP_GN_ROUTE_PIVOT_BLOCKS_128,
+    ENLSIP_GN_ROUTE_PIVOT_HYBRID,            /* kp > 512: launch-per-step head, then the register blocks               */
+    ENLSIP_GN_ROUTE_PIVOT_STEPS,             /* kp > 512 with ENLSIP_GN_QRCP_HYBRID=0: one launch per step to the end  */
+    ENLSIP_GN_ROUTE_PIPELINE_SPLIT,          /* batch >= 128: two halves on two streams                                */
+    ENLSIP_GN_ROUTE_CHUNKED,                 /* batch > 32768: consecutive chunks                                      */
+    ENLSIP_GN_ROUTE_SECOND_ATTEMPT,          /* some A was rank deficient: J2 wider than speculated, redone            */
+    ENLSIP_GN_ROUTE_RESCALED,                /* inputs beyond the range of plain sums of squares: solved on a copy     */
+                                             /* scaled by a power of two (LAPACK's dnrm2 / dlarfg behaviour)           */
+    ENLSIP_GN_ROUTE_COUNT
+};
+int enlsip_gn_get_route(enlsip_gn_handle h, uint64_t* mask);
+const char* enlsip_gn_route_name(int bit);
 /* Debugging aid (tests/probes/pair_probe_w*.py): copies the working matrix W of problem `prob` (ldw x (n + 1): J*Q1 with the CAQR factors of
  * [J2 | d] in place) as it stands to host memory; *ldw_out = its leading dimension; -3 when cap_doubles is too small.  Together with
  * ENLSIP_GN_DEBUG_MAXPAN / ENLSIP_GN_DEBUG_STAGE (stop the CAQR sweep after so many panels / inside the first pair) this is how an

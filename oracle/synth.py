@@ -69,12 +69,16 @@ def make_rank_deficient_A(problem_id: int, m: int, n: int, t: int):
 
 
 def make_graded_J(problem_id: int, m: int, n: int, t: int, log10_cond: float = 8.0):
-    """J with singular values 10^(-log10_cond * k / (n-1)), k = 0..n-1 (random orthogonal factors)."""
+    """J with singular values 10^(-log10_cond * k / (n-1)), k = 0..n-1 (random orthogonal factors).  A wide J (m < n) has
+    min(m, n) singular values: the first m of the same sequence (for m >= n nothing changes, bit for bit)."""
     J0, rx, A, cx = make_problem(problem_id, m, n, t)
-    U, _ = np.linalg.qr(J0)
+    U, _ = np.linalg.qr(J0)                 # m x min(m, n)
     G = normal_stream(problem_id, 4, n * n).reshape((n, n), order="F")
     V, _ = np.linalg.qr(G)
     s = 10.0 ** (-log10_cond * np.arange(n) / max(n - 1, 1))
+    k = min(m, n)
+    if k < n:
+        return (U * s[:k]) @ V[:, :k].T, rx, A, cx
     return (U * s) @ V.T, rx, A, cx
 
 

@@ -243,8 +243,11 @@ PROBLEMS = {"hs1": hs1, "hs2": hs2, "hs14": hs14, "hs15": hs15, "hs16": hs16, "h
             "hs52": hs52, "hs53": hs53, "hs60": hs60, "hs77": hs77, "hs79": hs79}
 
 
-# Not run: with more violated constraints than unknowns the swap loop of evaluate_violated_constraints at capacity
-# (src/enlsip_functions.jl:621-647, restated literally in oracle/enlsip_outer.py) exchanges the same two constraints forever.
+# Not run iteration for iteration: with more violated constraints than unknowns the swap loop of evaluate_violated_constraints
+# at capacity (src/enlsip_functions.jl:621-647) exchanges the same two constraints forever — remove_constraint! re-sorts the
+# inactive list (src/structures.jl:240), so the constraint just swapped out lands at the loop's index and add_constraint! puts
+# it straight back.  The Julia reference would spin there without a status; tests/test_hs_set.py proves the repeated state on
+# the literal restatement (test_hs20_hs23_spin_in_the_swap_loop_of_evaluate_violated_constraints).
 CYCLING = {"hs20": hs20, "hs23": hs23}
 
 # Runs that end away from the collection's solution with this algorithm (whatever the subproblem backend): HS2 in its second,

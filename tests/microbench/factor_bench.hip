@@ -1,7 +1,7 @@
 // Timing harness for the panel factorisation of the CAQR (k_caqr_factor<8,8>, gn_kernels_caqr.hpp) on the C2 geometry: `batch`
 // problems x 8 tiles of 512 x 32, timed with HIP events; the timing-only ablations (-DENLSIP_FACTOR_ABLATE=1..6, see the kernel
 // header) say where a step's time goes, -DENLSIP_FACTOR_STAMPS adds wall-clock stamps of one workgroup's phases.
-// Build: hipcc --offload-arch=gfx950 -O3 -w -std=c++17 -I enlsip.jl_amd/csrc -o tests/microbench/factor_bench tests/microbench/factor_bench.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -w -std=c++17 -DENLSIP_GN_LAB -I enlsip.jl_amd/csrc -o tests/microbench/factor_bench tests/microbench/factor_bench.hip
 // Run  : factor_bench [batch=384] [tiles=8]
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -2,7 +2,7 @@
 // (gn_kernels_update_v4.hpp) on synthetic data with the C2 geometry; the reflector-by-reflector kernel
 // of gn_kernels_caqr.hpp is timed beside it.  The check recomputes C - V (T' (V' C)) in plain host loops
 // for sampled columns of problem 0.
-// Build: hipcc --offload-arch=gfx950 -O3 -w -std=c++17 -I enlsip.jl_amd/csrc -o tests/microbench/update_bench tests/microbench/update_bench.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -w -std=c++17 -DENLSIP_GN_LAB -I enlsip.jl_amd/csrc -o tests/microbench/update_bench tests/microbench/update_bench.hip
 //        (-DENLSIP_V4_ABLATE=2|3|4|5 for the timing-only ablations documented in the kernel header, -DENLSIP_V4_STAMPS for
 //        per-phase wall-clock stamps of sample workgroups; the stamps themselves cost ~25 %)
 // Run  : update_bench [batch=256] [panel=0] [level=0]

@@ -1,5 +1,5 @@
 """Diagnostic (GPU box, stamps build): phase times of a pivot step of the blocked pivoted QR, single C2 problem and batch.
-   bash enlsip.jl_amd/build.sh -DENLSIP_SB_STEP_STAMPS -o enlsip.jl_amd/lib/libenlsip_gn_stamps.so
+   bash enlsip.jl_amd/build.sh -DENLSIP_GN_LAB -DENLSIP_SB_STEP_STAMPS -o enlsip.jl_amd/lib/libenlsip_gn_stamps.so
    ENLSIP_GN_LIB=enlsip.jl_amd/lib/libenlsip_gn_stamps.so python tests/probes/sb_step_probe.py [batch]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "enlsip.jl_amd", "python"))

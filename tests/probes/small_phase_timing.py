@@ -1,5 +1,5 @@
 """Phase timing of the wave-per-problem pivot stage (diagnostic, not a test).  Needs the timing-only build
-`bash enlsip.jl_amd/build.sh -DGN_PS_STAMPS`, which makes k_pivot_small overwrite the last entries of d_out of problem 0
+`bash enlsip.jl_amd/build.sh -DENLSIP_GN_LAB -DGN_PS_STAMPS`, which makes k_pivot_small overwrite the last entries of d_out of problem 0
 with 100 MHz wall-clock stamps.  usage: python3 tests/probes/small_phase_timing.py m n t batch"""
 import sys, os
 sys.path.insert(0, os.path.join(os.getcwd(), "enlsip.jl_amd", "python")); sys.path.insert(0, os.getcwd())

@@ -188,6 +188,7 @@ def test_batch_above_launch_limit_small_shape(solver):
     B, m, n, t = 40000, 64, 8, 2
     J, rx, At, cx = wl.make_batch(100, B, m, n, t, "cuda:0")
     p, b, d, info, jJ = _solve_batch_dev(solver, J, rx, At, cx)
+    assert "chunked" in solver.route()
     _check_all_problems(J, rx, At, cx, p, d, info, chunk=20000)
     _check_sample_against_oracle(J, rx, At, cx, p, d, info, jJ, [0, 19999, 20000, 20001, B - 1])
 

@@ -113,6 +113,7 @@ def test_mfma_and_reflector_updates_agree(solver, solver_refl):
     J, rx, A, cx = synth.make_problem(321, 3000, 200, 10)
     a = solver.solve(J, rx, A, cx)
     b = solver_refl.solve(J, rx, A, cx)
+    assert {"sweep_reflectors", "jq1_plain"} <= solver_refl.route() and "sweep_reflectors" not in solver.route()
     assert rel(a.p, b.p) <= 1e-12 and np.array_equal(a.jpvtJ2, b.jpvtJ2)
     assert rel(np.abs(a.d[:190]), np.abs(b.d[:190])) <= 1e-11
 
@@ -168,6 +169,122 @@ def test_accessors(solver):
     R = fv.R
     G = J2[:, fv.p - 1].T @ J2[:, fv.p - 1]
     assert rel(R.T @ R, G) <= 1e-12
+
+
+EXTREME_SHAPES = [(300, 40, 6), (256, 32, 4), (700, 130, 20), (900, 300, 40), (600, 520, 30), (300, 200, 90)]
+EXTREME_SCALES = [(600, 0), (-600, 0), (0, 600), (0, -600), (600, -600), (-700, 700), (1000, 1000), (-990, 0)]
+
+
+@pytest.mark.parametrize("m,n,t", EXTREME_SHAPES)
+def test_extreme_magnitudes_match_lapack(m, n, t, solver):
+    """VERDICT round 4, "missing" 2: qr(., ColumnNorm()) of the reference is dgeqp3, whose norms (dnrm2) and reflectors (dlarfg)
+    scale internally — J * 2^600 or A * 2^-600 is factored like any other matrix, and pseudo_rank's FIRST test, which is absolute
+    (src/enlsip_functions.jl:19), then decides the rank: a J of magnitude 2^-600 has rankJ2 = 0, an A of that magnitude rankA = 0
+    and the stabilised path.  The kernels square plainly; the library detects the case on its result and solves again on copies
+    scaled by a power of two (gn_rescale.hpp).  Here: J, rx and A, cx scaled by powers of two far outside the range of plain sums
+    of squares, every combination, in every size class of the dispatch — ranks, code, pivots, p, b, |d|, |diag R| and R itself
+    against the oracle (real LAPACK) on the SAME scaled inputs; then the consumers of the resident factors."""
+    from enlsip_gn import FACTOR_A, FACTOR_L11, FACTOR_J2
+    J0, rx0, A0, cx0 = synth.make_problem(61000 + m + n, m, n, t)
+    for eJ, eA in EXTREME_SCALES:
+        J, rx, A, cx = np.ldexp(J0, eJ), np.ldexp(rx0, eJ), np.ldexp(A0, eA), np.ldexp(cx0, eA)
+        ref = go.gn_subproblem(J, rx, A, cx)
+        out = solver.solve(J, rx, A, cx)
+        tag = (m, n, t, eJ, eA)
+        assert "rescaled" in solver.route(), tag
+        assert (out.rankA, out.rankJ2, out.code, out.status) == (ref.rankA, ref.rankJ2, ref.code, 0), tag
+        assert np.array_equal(out.jpvtA, ref.jpvtA) and np.array_equal(out.jpvtL, ref.jpvtL), tag
+        r = ref.rankJ2
+        assert np.array_equal(out.jpvtJ2[:r], ref.jpvtJ2[:r]), tag
+        assert np.all(np.isfinite(out.p)) and rel(out.p, ref.p) <= 1e-11, (tag, rel(out.p, ref.p))
+        assert rel(out.b, ref.b) <= 1e-11, tag
+        assert abs(np.linalg.norm(np.ldexp(out.d, -eJ)) - np.linalg.norm(np.ldexp(ref.d, -eJ))) <= 1e-12 * np.linalg.norm(np.ldexp(ref.d, -eJ)), tag
+        for which, F, e in ((FACTOR_A, ref.F_A, eA), (FACTOR_L11, ref.F_L11, eA), (FACTOR_J2, ref.F_J2, eJ)):
+            fv = solver.factor(which)
+            kk = r if which == FACTOR_J2 else min(F.R.shape)          # beyond rankJ2 the pivots (and so the rows of R) are rounding's
+            if kk == 0:
+                continue
+            dg, dgr = np.ldexp(np.abs(fv.diagR()[:kk]), -e), np.ldexp(np.abs(F.diagR()[:kk]), -e)
+            assert np.abs(dg - dgr).max() <= 1e-11 * dgr.max(), (tag, which)
+            if which != FACTOR_J2 or r == min(F.R.shape):
+                assert rel(np.ldexp(np.abs(fv.R), -e), np.ldexp(np.abs(F.R), -e)) <= 1e-10, (tag, which)
+            v = np.linspace(-1.0, 1.0, F.rows)
+            assert rel(fv.Q_mul(fv.Qt_mul(v)), v) <= 1e-12, (tag, which)
+        # J * F_A.Q on the caller's (unscaled) J, and the re-solve with truncated dimensions on the resident factors
+        if abs(eJ) <= 700:
+            assert rel(np.ldexp(solver.JQ1(m, n), -eJ), np.ldexp(ref.F_A.rmul_Q(J), -eJ)) <= 1e-12, tag
+        if ref.rankA and ref.rankJ2 > 1:
+            dimA, dimJ2 = ref.rankA - 1, ref.rankJ2 // 2
+            JQ1 = ref.F_A.rmul_Q(J)
+            p_ref, b_ref, d_ref = go.sub_search_direction(JQ1[:, :ref.rankA], rx, cx, ref.F_A, ref.F_L11, ref.F_J2, n, t, ref.rankA, dimA, dimJ2, -1)
+            p2, b2, d2 = solver.resolve(m, n, t, dimA, dimJ2, -1)
+            assert rel(p2, p_ref) <= 1e-9 and rel(b2, b_ref) <= 1e-10, tag
+    # the next ordinary solve on the handle is an ordinary solve again
+    out = solver.solve(J0, rx0, A0, cx0)
+    assert "rescaled" not in solver.route() and rel(out.p, go.gn_subproblem(J0, rx0, A0, cx0).p) <= 1e-11
+
+
+def test_extreme_magnitudes_in_a_batch_and_in_the_factored_flow(solver):
+    """The same inside a batch — two of five problems far outside the range, each handed to a one-problem handle of its own, outputs
+    in the caller's slots, accessors routed — with mixed-scale COLUMNS in a third (column norms spread over 2^+-250: no rescaling,
+    plain arithmetic carries it), and in the factor_constraints / solve_factored flow of update_working_set's s == 0 branch."""
+    from enlsip_gn import FACTOR_A, FACTOR_J2
+    m, n, t, B = 300, 40, 6, 5
+    probs = [list(synth.make_problem(62000 + k, m, n, t)) for k in range(B)]
+    probs[1][0], probs[1][1] = np.ldexp(probs[1][0], 650), np.ldexp(probs[1][1], 650)              # J, rx huge
+    probs[3][2], probs[3][3] = np.ldexp(probs[3][2], -620), np.ldexp(probs[3][3], -620)            # A, cx tiny: rankA = 0
+    colscale = np.ldexp(1.0, np.linspace(-250, 250, n).round().astype(int))
+    probs[4][0] = probs[4][0] * colscale                                                            # mixed-scale columns
+    refs = [go.gn_subproblem(*P) for P in probs]
+    p, b, d, infos, jA, jL, jJ = solver.solve_batched(np.stack([np.ascontiguousarray(P[0].T) for P in probs]), np.stack([P[1] for P in probs]),
+                                                      np.stack([np.ascontiguousarray(P[2]) for P in probs]), np.stack([P[3] for P in probs]))
+    assert "rescaled" in solver.route()
+    for k, ref in enumerate(refs):
+        assert (infos[k][0], infos[k][1], infos[k][2], infos[k][5]) == (ref.rankA, ref.rankJ2, ref.code, 0), k
+        assert rel(p[k], ref.p) <= (1e-11 if k != 4 else 1e-9), (k, rel(p[k], ref.p))
+        assert rel(b[k], ref.b) <= 1e-11, k
+        r = ref.rankJ2
+        assert np.array_equal(jJ[k][:r], ref.jpvtJ2[:r]), k
+        fv = solver.factor(FACTOR_J2, prob=k)
+        dg, dgr = np.abs(fv.diagR()[:r]), np.abs(ref.F_J2.diagR()[:r])
+        assert np.abs(dg / dgr - 1.0).max() <= 1e-10, k
+        assert np.array_equal(solver.factor(FACTOR_A, prob=k).p, ref.F_A.p), k
+    # factored flow, A beyond the range
+    J, rx, A, cx = synth.make_problem(62100, 400, 60, 9)
+    for eJ, eA in ((0, 640), (0, -640), (610, -630)):
+        Js, rxs, As, cxs = np.ldexp(J, eJ), np.ldexp(rx, eJ), np.ldexp(A, eA), np.ldexp(cx, eA)
+        ref = go.gn_subproblem(Js, rxs, As, cxs)
+        rankA, code, dimA = solver.factor_constraints(400, As, cxs)
+        assert (rankA, code) == (ref.rankA, ref.code)
+        fa = solver.factor(FACTOR_A)
+        assert np.array_equal(fa.p, ref.F_A.p) and rel(np.ldexp(np.abs(fa.R), -eA), np.ldexp(np.abs(ref.F_A.R), -eA)) <= 1e-11
+        out = solver.solve_factored(Js, rxs, 9)
+        assert (out.rankA, out.rankJ2, out.code) == (ref.rankA, ref.rankJ2, ref.code)
+        assert rel(out.p, ref.p) <= 1e-11 and rel(out.b, ref.b) <= 1e-11
+
+
+@pytest.mark.parametrize("m,n,t", [(700, 48, 6), (900, 200, 70), (512, 256, 64), (300, 40, 0)])
+def test_matrix_times_QA_and_the_full_constraint_product(m, n, t, solver):
+    """`M * F_A.Q` for ANY matrix with the row count of the last solve (what the Julia glue's `*(::AbstractMatrix, ::DeviceQ)`
+    calls: the consumers' `J * F_A.Q`, src/enlsip_functions.jl:384, :526, :1249, unmodified) against the oracle's dormqr, and
+    `A * p` with the FULL constraint Jacobian — inactive rows included (:2227) — against NumPy."""
+    from enlsip_gn.api import GNError
+    J, rx, A, cx = synth.make_problem(4300 + m, m, n, t)
+    ref = go.gn_subproblem(J, rx, A, cx)
+    out = solver.solve(J, rx, A, cx)
+    assert rel(solver.matrix_times_QA(J), ref.F_A.rmul_Q(J)) <= 1e-12           # the resident J itself: get_JQ1's result
+    assert rel(solver.matrix_times_QA(J), solver.JQ1(m, n)) <= 1e-14
+    rng = np.random.default_rng(m)
+    M = rng.standard_normal((m, n))
+    assert rel(solver.matrix_times_QA(M), ref.F_A.rmul_Q(M)) <= 1e-12           # any other matrix of that row count
+    with pytest.raises(GNError):
+        solver.matrix_times_QA(M[: m - 1])
+    # the full constraint Jacobian: l rows of which only the first t are active
+    l = t + 9
+    Afull = np.vstack([A, rng.standard_normal((l - t, n))])
+    got = solver.full_constraints_times(Afull, out.p)
+    assert np.abs(got - Afull @ out.p).max() <= 1e-13 * (np.abs(Afull).sum(axis=1).max() * np.abs(out.p).max() + 1.0)
+    assert solver.full_constraints_times(np.zeros((0, n)), out.p).shape == (0,)
 
 
 @pytest.mark.parametrize("m,n,t,dims", [(600, 40, 6, ((6, 34), (4, 20), (0, 0), (6, 10))),

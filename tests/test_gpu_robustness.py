@@ -278,6 +278,7 @@ def test_lookahead_sweep_matches_the_one_stream_sweep(m, n, t, pair):
         try:
             for _ in range(2):                  # twice on one handle: events and the second stream are reused
                 out = s.solve(J, rx, A, cx)
+            assert ("sweep_lookahead" in s.route()) == bool(la)
             outs.append(out)
         finally:
             s.close()
@@ -318,6 +319,48 @@ def test_blocked_qrcp_form_hints_never_change_a_result():
         one.close()
 
 
+def _half_graded_problem(pid, m, n, t, flat):
+    """J whose first `flat` singular values are 1 and the rest fall by eight decades: the pivoted QR of R0 opens with long blocks
+    (32 steps each) and ends in many short ones (norm recomputations)."""
+    J0, rx, A, cx = synth.make_problem(pid, m, n, t)
+    U, _ = np.linalg.qr(J0)
+    V, _ = np.linalg.qr(synth.normal_stream(pid, 4, n * n).reshape((n, n), order="F"))
+    sv = np.ones(n)
+    sv[flat:] = 10.0 ** (-8.0 * np.arange(1, n - flat + 1) / (n - flat))
+    return (U * sv) @ V.T, rx, A, cx
+
+
+@pytest.mark.gpu
+def test_blocked_qrcp_slow_start_after_a_long_hinted_chunk():
+    """a solve with a fast start and a long tail of short blocks leaves (a) a large first chunk and (b) hints that
+    suppress the 448 / 256-row forms from the fifth block id on; the NEXT solve of the shape starts slowly (graded from the first
+    column: short blocks all the way), is still above 256 rows when the hints stop launching the large form, idles to the end of the
+    hinted chunk and falls back.  Until round 5 the fall-back gated the forms on kp - (blocks launched), found 'at most 250 rows'
+    and never launched the large form again: the loop ran out and the factors were assembled half done.  The forms are now gated on
+    an upper bound of the real row counts (run_qrcp_block: rows_bound).  Bit for bit against a handle without hints, and the oracle."""
+    from enlsip_gn import GNSolver
+    m, n, t = 1500, 330, 30            # kp = 300
+    fast_then_short = _half_graded_problem(7801, m, n, t, 170)
+    slow = synth.make_graded_J(7802, m, n, t)
+    one = GNSolver(device=0)
+    try:
+        for (J, rx, A, cx) in (fast_then_short, slow, fast_then_short, slow):
+            ref = go.gn_subproblem(J, rx, A, cx)
+            out = one.solve(J, rx, A, cx)
+            fresh = _solver_with_env(ENLSIP_GN_SB_FORM_HINTS=0)
+            try:
+                base = fresh.solve(J, rx, A, cx)
+            finally:
+                fresh.close()
+            assert np.array_equal(out.p, base.p) and np.array_equal(out.jpvtJ2, base.jpvtJ2) and out.rankJ2 == base.rankJ2
+            assert (out.rankA, out.rankJ2, out.code) == (ref.rankA, ref.rankJ2, ref.code)
+            r = ref.rankJ2
+            assert np.array_equal(out.jpvtJ2[:r], ref.jpvtJ2[:r])
+            assert rel(out.p, ref.p) <= 1e-5
+    finally:
+        one.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,t", [(900, 640, 20), (1100, 1024, 0), (700, 600, 88)])
 def test_hybrid_pivoted_qr_matches_the_launch_per_step_form(m, n, t):
@@ -334,6 +377,8 @@ def test_hybrid_pivoted_qr_matches_the_launch_per_step_form(m, n, t):
             s = _solver_with_env(ENLSIP_GN_QRCP_HYBRID=hyb)
             try:
                 outs.append(s.solve(J, rx, A, cx))
+                if min(m, n - t) > 512:
+                    assert ("pivot_hybrid" if hyb else "pivot_steps") in s.route()
             finally:
                 s.close()
         a, b = outs
@@ -369,11 +414,16 @@ def test_two_problem_waves_with_more_than_64_constraint_reflectors(m, n, t, batc
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("probe,count,seed", [("fuzz_batched", 30, 62), ("fuzz_gpu", 120, 71)])
+@pytest.mark.parametrize("probe,count,seed", [("fuzz_batched", 25, 62), ("fuzz_batched", 25, 5), ("fuzz_batched", 25, 19),
+                                              ("fuzz_gpu", 100, 71), ("fuzz_gpu", 100, 3), ("fuzz_gpu", 100, 29),
+                                              ("fuzz_accessors", 30, 1), ("fuzz_accessors", 30, 2), ("fuzz_accessors", 30, 3),
+                                              ("fuzz_tsqr", 6, 1), ("fuzz_tsqr", 6, 2), ("fuzz_tsqr", 6, 3)])
 def test_randomised_shapes_against_the_oracle(probe, count, seed, monkeypatch):
     """The randomised sweeps of tests/probes (mixed batches: full rank, rank-deficient A / J2, graded J2, zero A; single problems of
-    every size class) as part of the suite, one fixed seed each — seed 62 of the batched sweep is the one that found the defect
-    pinned by test_two_problem_waves_with_more_than_64_constraint_reflectors."""
+    every size class; the accessors and the re-solve on random shapes; row-sharded TSQR solves) as part of the suite, three fixed
+    seeds each — seed 62 of the batched sweep is the one that found the defect pinned by
+    test_two_problem_waves_with_more_than_64_constraint_reflectors.  The shapes that cross every kernel-selection boundary are
+    not left to chance: tests/test_dispatch_grid.py."""
     import importlib.util, pathlib, sys
     path = pathlib.Path(__file__).resolve().parent / "probes" / (probe + ".py")
     spec = importlib.util.spec_from_file_location("probe_" + probe, path)

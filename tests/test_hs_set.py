@@ -34,6 +34,60 @@ def test_hs_oracle_backend_reaches_the_published_solution(name):
         assert np.abs(P["eq"](res.x)).max() <= 1e-7
 
 
+class _SwapCycle(Exception):
+    pass
+
+
+@pytest.mark.parametrize("name", list(hp.CYCLING))
+def test_hs20_hs23_spin_in_the_swap_loop_of_evaluate_violated_constraints(name, monkeypatch):
+    """HS20 and HS23 are not in the iteration-for-iteration set, and this is why — read from the reference's code, since the
+    reference cannot be run here.  `evaluate_violated_constraints` (src/enlsip_functions.jl:608-650) walks the inactive list with
+    an index `i`; at capacity (`W.t >= min(l, n)`: both problems have more violated constraints than unknowns) it swaps the
+    least violated active inequality out (`remove_constraint!(W, worst_k)`, :636) and then adds `W.inactive[i]` (:642).  But
+    `remove_constraint!` (src/structures.jl:234-249) SORTS the inactive list after appending the constraint it removed: when that
+    constraint's number is smaller than the candidate's, it lands AT position `i`, `add_constraint!(W, i)` puts it straight back,
+    the candidate moves to position `i` again, and the loop meets the very state it started from — `i` never advances, there is no
+    iteration bound inside the loop, and `time_limit` is only looked at between outer iterations (:2752).  The Julia reference
+    would therefore spin here for ever (no status, no exception); the literal restatement (oracle/enlsip_outer.py) does the same,
+    which this test proves by catching the first repeated (active, inactive, i) state inside ONE call.  Whatever backend solves
+    the subproblem is irrelevant: the loop only reads constraint values."""
+    from oracle import enlsip_outer as eo
+    orig = eo.evaluate_violated_constraints
+    calls = {"n": 0}
+
+    def watched(cx, W, index_alpha_upp, n, ws_mod):
+        seen = set()
+        calls["n"] += 1
+
+        class Proxy:
+            Constraint = getattr(ws_mod, "Constraint", None)
+
+            @staticmethod
+            def remove_constraint(Wx, sidx):
+                ws_mod.remove_constraint(Wx, sidx)
+
+            @staticmethod
+            def add_constraint(Wx, sidx):
+                state = (tuple(int(v) for v in Wx.active), tuple(int(v) for v in Wx.inactive), int(Wx.t), int(sidx))
+                if state in seen:
+                    raise _SwapCycle(state)
+                seen.add(state)
+                ws_mod.add_constraint(Wx, sidx)
+
+        return orig(cx, W, index_alpha_upp, n, Proxy)
+
+    monkeypatch.setattr(eo, "evaluate_violated_constraints", watched)
+    P = dict(hp.CYCLING[name]())
+    kw = dict(P.pop("kw"))
+    P.pop("x_star"); P.pop("f_star")
+    with pytest.raises(_SwapCycle) as exc:
+        eo.solve(P.pop("r"), P.pop("jac_r"), P.pop("n"), P.pop("m"), P.pop("x0"), backend=eo.OracleBackend(), time_limit=30.0, **P, **kw)
+    active, inactive, t, i = exc.value.args[0]
+    n_unknowns = 2
+    # the repeated state sits between the removal and the re-insertion: one below capacity (min(l, n) = n = 2 here)
+    assert t == n_unknowns - 1 and calls["n"] >= 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(hp.PROBLEMS))
 def test_hs_hip_backend_iteration_for_iteration(name):
