@@ -454,8 +454,25 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
     const bool deep = la && h->la_deep;
     hipStream_t sC = nullptr, sD = nullptr;
     if (deep) {
-        if (!h->stream3) GN_HIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-        if (!h->stream4) GN_HIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+        // HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4 per priority class), each new stream on
+        // the least used one: with the process's other streams around, sD landed on sA's queue and ran in FIFO order behind it
+        // (measured: the chain as long as on one stream).  The highest priority class is no way out — its dispatches preempt the
+        // running waves of every other queue (context save / restore: the tile factorisation on sA 95 -> 275 us).  A stream
+        // created with a compute-unit mask owns a hardware queue of its own: sC and sD are such streams with EVERY unit enabled.
+        auto own_queue_stream = [&](hipStream_t* st) -> int {
+            if (*st) return 0;
+            uint32_t mask[32];
+            const int words = std::min(32, (h->cu_count + 31) / 32);
+            for (int i = 0; i < words; ++i) mask[i] = 0xFFFFFFFFu;
+            if (h->cu_count % 32) mask[words - 1] = (1u << (h->cu_count % 32)) - 1u;
+            if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask) == hipSuccess) return 0;
+            (void)hipGetLastError();
+            *st = nullptr;
+            GN_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+            return 0;
+        };
+        if (int rc = own_queue_stream(&h->stream3)) return rc;
+        if (int rc = own_queue_stream(&h->stream4)) return rc;
         sC = h->stream3;
         sD = h->stream4;
     }
