@@ -445,45 +445,11 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         sB = h->stream2;
         GN_ROUTE(ENLSIP_GN_ROUTE_SWEEP_LOOKAHEAD);
     }
-    // Deep look-ahead (round 5, paired sweeps only): the chain of a pair is itself a small task graph, and three of its edges do not
-    // exist — the tree of the first panel only needs that panel's tile factors, so it runs BESIDE the update of the second panel's
-    // columns and that panel's tile factorisation; the pair pass over the next pair's columns only needs the two tile factorisations,
-    // so it runs beside the second panel's tree; and the next pair's first panel only needs the FIRST 32 of those 64 columns, so
-    // the updates of the other 32 run beside its factorisation.  Two more streams (sC, sD), events for the edges.  Per pair of
-    // C4 the chain was 1.27 ms of 19 launches in a row (profiles/r4_notes.md, last section).
-    const bool deep = la && h->la_deep;
-    hipStream_t sC = nullptr, sD = nullptr;
-    if (deep) {
-        // HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4 per priority class), each new stream on
-        // the least used one: with the process's other streams around, sD landed on sA's queue and ran in FIFO order behind it
-        // (measured: the chain as long as on one stream).  The highest priority class is no way out — its dispatches preempt the
-        // running waves of every other queue (context save / restore: the tile factorisation on sA 95 -> 275 us).  A stream
-        // created with a compute-unit mask owns a hardware queue of its own: sC and sD are such streams with EVERY unit enabled.
-        auto own_queue_stream = [&](hipStream_t* st) -> int {
-            if (*st) return 0;
-            uint32_t mask[32];
-            const int words = std::min(32, (h->cu_count + 31) / 32);
-            for (int i = 0; i < words; ++i) mask[i] = 0xFFFFFFFFu;
-            if (h->cu_count % 32) mask[words - 1] = (1u << (h->cu_count % 32)) - 1u;
-            if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask) == hipSuccess) return 0;
-            (void)hipGetLastError();
-            *st = nullptr;
-            GN_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-            return 0;
-        };
-        if (int rc = own_queue_stream(&h->stream3)) return rc;
-        if (int rc = own_queue_stream(&h->stream4)) return rc;
-        sC = h->stream3;
-        sD = h->stream4;
-    }
-    hipEvent_t deep_c = nullptr, deep_d = nullptr;      // last work on sC / sD this stream has not waited for yet
     auto la_join = [&]() -> int {                 // this stream goes on only after the second stream's last far update
         if (la_prev) {
             GN_HIP(hipStreamWaitEvent(sA, la_prev, 0));
             la_prev = nullptr;
         }
-        if (deep_c) { GN_HIP(hipStreamWaitEvent(sA, deep_c, 0)); deep_c = nullptr; }
-        if (deep_d) { GN_HIP(hipStreamWaitEvent(sA, deep_d, 0)); deep_d = nullptr; }
         return 0;
     };
     for (int k = 0; k < npan;) {
@@ -509,96 +475,6 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             // far launches of pairs 1, 3, 5 of a C2 step (profiles/r4_notes.md).  The exact grid has an odd y extent.
             const int far_grid = mixed ? ntrail : nfar;
             auto live = [&](int st) { return h->debug_stage < 0 || st <= h->debug_stage; };   // ENLSIP_GN_DEBUG_STAGE (debugging aid)
-            if (deep) {
-                // segments of the far window: the next pair's first panel [0, 32), its second panel [32, 64), the rest
-                const int na = std::min(PB, nfar), nb = std::min(PB, nfar - na), nrest = nfar - na - nb;
-                auto ev = [&](hipEvent_t& e, hipStream_t st) -> int {
-                    if (int rc = la_event(e)) return rc;
-                    GN_HIP(hipEventRecord(e, st));
-                    return 0;
-                };
-                auto far_l0 = [&](int sub0, int ncw, hipStream_t st) -> int {        // both level-0 reflectors on far columns [sub0, sub0 + ncw)
-                    CaqrArgs a = caqr_args(h, k, LA[0]);
-                    a.win = 2; a.pair = 1; a.tOff2 = LB[0].tOff; a.sub0 = sub0; a.subn = ncw;
-                    const bool has_rhs = (sub0 + ncw == nfar);
-                    return timed(btrail(k, ncw) + btrail(kb, ncw), st, [&] {
-                        if (has_rhs) update_l0(a, LA[0], ncw, ncw, st);
-                        else launch_update_v4(h->plan.RPL, a, LA[0].groups, ncw, (int)P.batch, st);
-                    });
-                };
-                auto far_tree = [&](int kk, const std::vector<LevelPlan>& LV, int win, int sub0, int ncw, hipStream_t st) -> int {
-                    for (size_t li = 1; li < LV.size(); ++li) {
-                        CaqrArgs t = caqr_args(h, kk, LV[li]);
-                        t.win = win; t.sub0 = sub0; t.subn = ncw;
-                        if (int rc2 = other(st, [&] { launch_update_v4(h->plan.RPL, t, LV[li].groups, ncw, (int)P.batch, st); })) return rc2;
-                    }
-                    return 0;
-                };
-                hipEvent_t eA, eB, eC, eE, eF, eNa, e2 = nullptr;
-                // sA: tile factorisation of the first panel (everything of the previous pair on its 32 columns ran on sA)
-                { CaqrArgs a = caqr_args(h, k, LA[0]); launch_factor(h, a, LA[0].groups, sA); }
-                if (int rc = ev(eA, sA)) return rc;
-                // sA: ... applied to the second panel's columns (the previous pair's updates of THOSE columns ran on sD)
-                if (deep_d) { GN_HIP(hipStreamWaitEvent(sA, deep_d, 0)); deep_d = nullptr; }
-                {
-                    CaqrArgs a = caqr_args(h, k, LA[0]);
-                    a.win = 1;
-                    if (int rc = other(sA, [&] { launch_update_v4(h->plan.RPL, a, LA[0].groups, bwb, (int)P.batch, sA); })) return rc;
-                }
-                if (int rc = ev(eB, sA)) return rc;
-                // sC: the first panel's tree, each level applied to the second panel's columns (rows 0..31 of the tiles) — beside
-                //     sA: the second panel's tile factorisation (rows 32.. of the tiles)
-                GN_HIP(hipStreamWaitEvent(sC, eA, 0));
-                for (size_t li = 1; li < LA.size(); ++li) {
-                    CaqrArgs a = caqr_args(h, k, LA[li]);
-                    launch_factor(h, a, LA[li].groups, sC);
-                    if (li == 1) GN_HIP(hipStreamWaitEvent(sC, eB, 0));
-                    a.win = 1;
-                    if (int rc = other(sC, [&] { launch_update_v4(h->plan.RPL, a, LA[li].groups, bwb, (int)P.batch, sC); })) return rc;
-                }
-                if (int rc = ev(eE, sC)) return rc;
-                { CaqrArgs a = caqr_args(h, kb, LB[0]); launch_factor(h, a, LB[0].groups, sA); }
-                if (int rc = ev(eC, sA)) return rc;
-                // sA: the second panel's tree (needs the first panel's tree on its columns) — beside
-                // sC: the pair pass over the next pair's FIRST panel (needs both tile factorisations and the previous pair's rest)
-                GN_HIP(hipStreamWaitEvent(sA, eE, 0));
-                for (size_t li = 1; li < LB.size(); ++li) {
-                    CaqrArgs a = caqr_args(h, kb, LB[li]);
-                    launch_factor(h, a, LB[li].groups, sA);
-                }
-                if (int rc = ev(eF, sA)) return rc;
-                GN_HIP(hipStreamWaitEvent(sC, eC, 0));
-                if (la_prev) GN_HIP(hipStreamWaitEvent(sC, la_prev, 0));
-                if (int rc = far_l0(0, na, sC)) return rc;
-                if (int rc = ev(eNa, sC)) return rc;
-                // sD: the next pair's SECOND panel: pair pass, then both trees — beside everything that follows on sA up to the
-                //     next pair's update of those columns
-                if (nb > 0) {
-                    GN_HIP(hipStreamWaitEvent(sD, eC, 0));
-                    if (la_prev) GN_HIP(hipStreamWaitEvent(sD, la_prev, 0));
-                    if (int rc = far_l0(na, nb, sD)) return rc;
-                    GN_HIP(hipStreamWaitEvent(sD, eF, 0));                   // (eF follows eE on sA: both trees are complete)
-                    if (int rc = far_tree(k, LA, 2, na, nb, sD)) return rc;
-                    if (int rc = far_tree(kb, LB, 0, na, nb, sD)) return rc;
-                    if (int rc = ev(deep_d, sD)) return rc;
-                }
-                // sA: both trees on the next pair's first panel: the next tile factorisation follows on this stream
-                GN_HIP(hipStreamWaitEvent(sA, eNa, 0));
-                if (int rc = far_tree(k, LA, 2, 0, na, sA)) return rc;
-                if (int rc = far_tree(kb, LB, 0, 0, na, sA)) return rc;
-                // sB: the rest of the far window (lowest priority, the bulk of the flops)
-                if (nrest > 0) {
-                    GN_HIP(hipStreamWaitEvent(sB, eF, 0));
-                    if (int rc = far_l0(na + nb, nrest, sB)) return rc;
-                    if (int rc = far_tree(k, LA, 2, na + nb, nrest, sB)) return rc;
-                    if (int rc = far_tree(kb, LB, 0, na + nb, nrest, sB)) return rc;
-                    if (int rc = ev(e2, sB)) return rc;
-                }
-                la_prev = e2;          // nullptr when nothing was left for sB: its earlier work has been waited for by sC / sD
-                deep_c = nullptr;      // sC's last work (eNa) has been waited for on sA
-                k += 2;
-                continue;
-            }
             if (live(0)) {   // level 0 of the first panel, applied to the second panel's columns only
                 CaqrArgs a = caqr_args(h, k, LA[0]);
                 launch_factor(h, a, LA[0].groups);
@@ -1464,8 +1340,6 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         const char* lk = getenv("ENLSIP_GN_LOOKAHEAD");      // 0: the pair sweep on one stream (A/B)
         if (lk && lk[0] == '0') h->lookahead = false;
         if (lk && lk[0] == '1') h->lookahead_forced = true;   // 1: for every paired sweep (tests)
-        const char* ld = getenv("ENLSIP_GN_LA_DEEP");        // 0: look-ahead with one chain stream (the round-4 schedule; A/B, tests)
-        if (ld && ld[0] == '0') h->la_deep = false;
         const char* fs = getenv("ENLSIP_GN_FUSE_SMALL");     // 0: J*Q1 and the one-tile panel factorisation as two launches (A/B)
         if (fs && fs[0] == '0') h->fuse_small = false;
         const char* fh = getenv("ENLSIP_GN_SB_FORM_HINTS");   // 0: every block of the blocked pivoted QR in all of its forms (A/B)
@@ -1516,8 +1390,6 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);      // look-ahead sweep: an error return may have left work there
-    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
-    if (h->stream4) (void)hipStreamSynchronize(h->stream4);
     if (h->ws.p) (void)hipFree(h->ws.p);
     if (h->in_stage.p) (void)hipFree(h->in_stage.p);
     if (h->out_stage.p) (void)hipFree(h->out_stage.p);
@@ -1542,8 +1414,6 @@ int enlsip_gn_destroy(enlsip_gn_handle h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    if (h->stream3) (void)hipStreamDestroy(h->stream3);
-    if (h->stream4) (void)hipStreamDestroy(h->stream4);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;

@@ -103,8 +103,6 @@ struct enlsip_gn_context {
     bool lookahead_forced = false;
     bool lookahead = true;              // ENLSIP_GN_LOOKAHEAD=0: chain-bound pair sweeps on one stream
     hipStream_t stream2 = nullptr;      // second stream of the look-ahead sweep (the bulk of a pair's far update)
-    hipStream_t stream3 = nullptr, stream4 = nullptr;   // deep look-ahead: the first panel's tree + the next pair's first-panel columns / its second-panel columns
-    bool la_deep = true;                // ENLSIP_GN_LA_DEEP=0: the round-4 schedule (one chain stream + the bulk stream)
     std::vector<hipEvent_t> la_events;
     bool fuse_small = true;             // ENLSIP_GN_FUSE_SMALL=0: two launches for J*Q1 + panel factorisation of one-tile problems
     int factor_nw4 = 0;                 // ENLSIP_GN_FACTOR_NW4 (A/B): 1 = level-0 tiles factored by 4 waves x 8 columns, 2 = tree nodes too

@@ -1,0 +1,10 @@
+# C4: one bulk workgroup per compute unit (dynamic LDS pad on the bulk far update) against two (GPU box)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=${1:-gpurun_out/r5d}; mkdir -p $O
+for i in 1 2; do
+  for pad in 0 6144; do
+    ENLSIP_GN_BULK_PAD=$pad timeout -k 10 300 python3 bench.py --config C4 --steps 5 --cpu-budget 0 2> $O/c4_pad${pad}_$i.err | python3 tests/probes/bench_fields.py pad $pad >> $O/c4_ab.txt
+  done
+done
+cat $O/c4_ab.txt
+ENLSIP_GN_BULK_PAD=6144 timeout -k 10 400 bash tests/probes/trace_c4.sh $O/c4trace > $O/trace.log 2>&1; tail -n 70 $O/trace.log
