@@ -112,16 +112,14 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
     const unsigned jlane = (unsigned)(((size_t)lq * a.ldj + NP * lr) * 8);     // row (pair) NP lr, column lq of a 4-column step
     const unsigned wlane = (unsigned)(((size_t)lq * ldw + NP * lr) * 8);
     // p1 entries of the wave's first tile (columns < kA = 64 live in tiles 0..3 = T 0 of every wave) and the rx entry of the
-    // final row: fetched here so that the epilogue has no load queued behind its own stores (loads and stores retire in
-    // order under vmcnt: a load after 32 tile stores waits for their HBM acknowledgements)
+    // final row: the epilogue must have no load queued behind its own stores (loads and stores retire in order under vmcnt: a
+    // load after 32 tile stores waits for their HBM acknowledgements).  Until round 5 they were fetched here, at kernel entry,
+    // and their ten registers were live through both products: the <8, 4, 2> instance (C2) spilled four J values (76 B of scratch,
+    // reloaded in the middle of product 1).  They are now requested at the start of the LAST tile of product 3, when the
+    // accumulators of product 1 are long dead: the epilogue still finds them arrived, and nothing spills.
     static_assert(16 * Q2_NW >= KBLK, "p1 columns must lie in the first tile of every wave");
     double pcv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int col = 16 * w + lq + 4 * r;
-        pcv[r] = (col < rankA) ? p1[col < rankA ? col : 0] : 0.0;
-    }
-    const double rxv = (tid < Q2_RB) ? rx[row0 + tid] : 0.0;
+    double rxv = 0.0;
     double jt[NTW][4][NP];
 #pragma unroll
     for (int T = 0; T < NTW; ++T)
@@ -279,6 +277,14 @@ __global__ __launch_bounds__(64 * Q2_NW, 2) void k_jq1_v2(JQ1Args a) {
 #pragma unroll
             for (int T = 0; T < NTW; ++T) {
                 const int tile = w + Q2_NW * T;
+                if (T == NTW - 1) {                        // the epilogue's small operands (see the top of the kernel)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = 16 * w + lq + 4 * r;
+                        pcv[r] = (col < rankA) ? p1[col < rankA ? col : 0] : 0.0;
+                    }
+                    rxv = (tid < Q2_RB) ? rx[row0 + tid] : 0.0;
+                }
                 if (tile_on(T)) {
                     put_vt(tile, vx);
                     if (tile_on(T + 1)) fetch_vt(tile + Q2_NW, vx);
