@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64, (NR == 32 && ENLSIP_CS_OCC) ? ENLSIP_CS_OCC : (
         // (k_jq1_rows*, k_jq1_factor_small: the diagonal; launch_jq1 of the accessors: the upper triangle of the first kA columns),
         // so only those columns are written — 30 of the 32 KB per problem at C5 (t = 4) were zeros nobody reads: 250 MB per step
         double* T = a.TA + prob * a.sTA;
-        const int jcols = (kA <= Q1R_MAXK) ? kA : KBLK;
+        const int jcols = jq1_by_reflectors(n, kA) ? kA : KBLK;       // the predicate of launch_jq1_rows
         for (int jc = 0; jc < jcols; ++jc) T[ln + jc * KBLK] = (jc < kA && ln <= jc) ? Tl[ln + 64 * jc] : 0.0;
     }
     const int rankA = wave_pseudo_rank(dg, kA, a.eps_rank, ln, pseudo_rank_abs_threshold(a.eps_rank, a.abs_shift));

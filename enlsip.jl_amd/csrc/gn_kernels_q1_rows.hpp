@@ -10,6 +10,10 @@
 namespace gn {
 
 constexpr int Q1R_MAXK = 16;
+// ONE predicate for "J*Q1 of this shape runs reflector by reflector (k_jq1_rows*, k_jq1_factor_small)": the dispatch below
+// and the writer of the T block of Q1 (k_constraint_small, which then writes only the kA columns those kernels and the accessors
+// read instead of the 64 the compact-WY kernels need) must agree on it.
+__host__ __device__ inline bool jq1_by_reflectors(int n, int kA) { return n <= 64 && kA <= Q1R_MAXK; }
 
 template <int NMAX>
 #ifndef ENLSIP_JR_OCC
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256, 3) void k_jq1_rows2(JQ1Args a) {
 
 // Returns false when the shape is outside this kernel's range (the caller falls through to the compact-WY kernels).
 inline bool launch_jq1_rows(const JQ1Args& a, int batch, hipStream_t s) {
-    if (a.n > 64 || a.kA > Q1R_MAXK) return false;
+    if (!jq1_by_reflectors(a.n, a.kA)) return false;
     const dim3 grid((a.ldw + 255) / 256, batch);
 #ifdef ENLSIP_GN_LAB
     static const bool two = !(getenv("ENLSIP_GN_JQ1_ROWS2") && getenv("ENLSIP_GN_JQ1_ROWS2")[0] == '0');      // A/B switch

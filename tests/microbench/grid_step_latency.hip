@@ -42,8 +42,11 @@ __device__ __forceinline__ void st8_l2(double* p, double v) { asm volatile("glob
 __device__ __forceinline__ double ld8(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st8(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+constexpr int POLL_LIMIT = 1 << 22;          // ~ a second of polling: then the round is abandoned and the host prints the failure
+__device__ int g_gave_up;
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_rounds(Rec* recs, double* cols, unsigned* counter, int G, int steps, int rows, double* sink, int* xcc) {
+    int* gave_up = &g_gave_up;
     __shared__ int win_s;
     if (VARIANT == 2 && (blockIdx.x & 7)) return;          // one XCD: workgroups are dealt round-robin to the 8 XCDs
     const int g = VARIANT == 2 ? blockIdx.x >> 3 : blockIdx.x, tid = threadIdx.x, ln = tid & 63, w = tid >> 6;
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(256) void k_rounds(Rec* recs, double* cols, unsigne
             if (VARIANT == 0 || VARIANT == 2) {
                 bool all;
                 double bv; int bp;
+                int spins = 0;           // every poll loop is bounded: a record that never arrives ends the kernel, not the box
                 do {
                     bv = -1.0; bp = -1;
                     bool ok = true;
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(256) void k_rounds(Rec* recs, double* cols, unsigne
                         if (r.val > bv) { bv = r.val; bp = r.pos; }
                     }
                     all = __all(ok);
+                    if (++spins > POLL_LIMIT) { if (ln == 0) atomicExch(gave_up, 1); all = true; }
                 } while (!all);
                 for (int o = 32; o > 0; o >>= 1) {
                     const double ov = __shfl_xor(bv, o); const int op = __shfl_xor(bp, o);
@@ -94,7 +99,12 @@ __global__ __launch_bounds__(256) void k_rounds(Rec* recs, double* cols, unsigne
                 }
                 win = bp;
             } else {
-                if (ln == 0) while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G * (j + 1)) {}
+                if (ln == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G * (j + 1)) {
+                        if (++spins > POLL_LIMIT) { atomicExch(gave_up, 1); break; }
+                    }
+                }
                 __threadfence();
                 double bv = -1.0; int bp = -1;
                 for (int e = ln; e < G; e += 64) {
@@ -131,6 +141,11 @@ __global__ __launch_bounds__(256) void k_rounds(Rec* recs, double* cols, unsigne
 
 int main(int argc, char** argv) {
     const int G = argc > 1 ? atoi(argv[1]) : 129, steps = argc > 2 ? atoi(argv[2]) : 1000, rows = argc > 3 ? atoi(argv[3]) : 1024;
+    {   // every variant needs all of its workgroups resident at once: refuse a G the device cannot hold
+        hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+        const int cap = prop.multiProcessorCount * 2;           // 256-thread workgroups at the kernels' register budget: two per compute unit
+        if (G > cap) { printf("G = %d exceeds the resident-workgroup capacity (%d)\n", G, cap); return 2; }
+    }
     Rec* recs; double *cols, *sink; unsigned* ctr; int* xcc;
     CK(hipMalloc(&recs, sizeof(Rec) * 2 * G)); CK(hipMalloc(&cols, sizeof(double) * 2 * G * rows)); CK(hipMalloc(&sink, 8)); CK(hipMalloc(&ctr, 4));
     CK(hipMalloc(&xcc, 4 * G));
@@ -148,6 +163,9 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e1));
             CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            int gave_up = 0, zero = 0;
+            CK(hipMemcpyFromSymbol(&gave_up, HIP_SYMBOL(g_gave_up), 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gave_up), &zero, 4));
+            if (gave_up) { printf("variant %d: a poll loop ran into its limit (records never arrived): no figure\n", variant); continue; }
             printf("variant %d (%s) G %d rows %d: %.3f us per round\n", variant, variant == 2 ? "ONE XCD, tagged records, L2-coherent ld/st" : (variant ? "fence + atomic counter" : "tagged records, coherent ld/st"), G, rows, ms * 1e3 / steps);
             fflush(stdout);
         }
