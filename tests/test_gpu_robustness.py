@@ -417,11 +417,12 @@ def test_two_problem_waves_with_more_than_64_constraint_reflectors(m, n, t, batc
 @pytest.mark.parametrize("probe,count,seed", [("fuzz_batched", 25, 62), ("fuzz_batched", 25, 5), ("fuzz_batched", 25, 19),
                                               ("fuzz_gpu", 100, 71), ("fuzz_gpu", 100, 3), ("fuzz_gpu", 100, 29),
                                               ("fuzz_accessors", 30, 1), ("fuzz_accessors", 30, 2), ("fuzz_accessors", 30, 3),
-                                              ("fuzz_tsqr", 6, 1), ("fuzz_tsqr", 6, 2), ("fuzz_tsqr", 6, 3)])
+                                              ("fuzz_tsqr", 6, 1), ("fuzz_tsqr", 6, 2), ("fuzz_tsqr", 6, 3),
+                                              ("fuzz_magnitudes", 40, 1), ("fuzz_magnitudes", 40, 2), ("fuzz_magnitudes", 40, 3)])
 def test_randomised_shapes_against_the_oracle(probe, count, seed, monkeypatch):
     """The randomised sweeps of tests/probes (mixed batches: full rank, rank-deficient A / J2, graded J2, zero A; single problems of
-    every size class; the accessors and the re-solve on random shapes; row-sharded TSQR solves) as part of the suite, three fixed
-    seeds each — seed 62 of the batched sweep is the one that found the defect pinned by
+    every size class; the accessors and the re-solve on random shapes; row-sharded TSQR solves; random shapes at random power-of-two
+    scales far outside the range of plain sums of squares: the rescale path) as part of the suite, three fixed seeds each — seed 62 of the batched sweep is the one that found the defect pinned by
     test_two_problem_waves_with_more_than_64_constraint_reflectors.  The shapes that cross every kernel-selection boundary are
     not left to chance: tests/test_dispatch_grid.py."""
     import importlib.util, pathlib, sys
