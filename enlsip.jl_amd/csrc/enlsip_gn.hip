@@ -396,6 +396,9 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
         if (e1) GN_HIP(hipEventRecord(e1, st));
         return 0;
     };
+    // few problems with many tiles each: the far update of a pair reads its grid XCD-locally, so that a tile's V stays in one L2
+    // between the tile's column blocks (k_caqr_update_v4_pair); batches keep the native order (a problem's tiles are neighbours)
+    auto xmap_tiles = [&](int groups) -> int { return (h->xcd_map && P.batch <= 8 && groups >= 16 && !mixed) ? groups : 0; };
     auto btrail = [&](int k, double ncols) { const double mk = mpad - (double)k * PB; return 8.0 * (2.0 * mk * ncols + mk * PB + PB * PB); };
     // the MFMA update of every trailing column of the window; with the J2 columns filling whole 32-column blocks the carried
     // right-hand side (the 32 j + 1-th column: every panel of C2) would take a block of its own: it gets its own routine as the
@@ -511,6 +514,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
                     const int ncw = (subn > 0 ? std::min(subn, nfar - sub0) : nfar - sub0);     // launch shape of the sub-window
                     CaqrArgs a = caqr_args(h, k, LA[0]);
                     a.win = 2; a.pair = 1; a.tOff2 = LB[0].tOff; a.sub0 = sub0; a.subn = subn;
+                    a.xmap = xmap_tiles(LA[0].groups);
                     // the carried right-hand side is the window's last column: a sub-window that ends before it has J2 columns only
                     const bool has_rhs = (sub0 + ncw == nfar);
                     const double by = btrail(k, ncw) + btrail(kb, ncw);
@@ -552,6 +556,7 @@ static int run_caqr(enlsip_gn_handle h, int n2_launch) {
             } else {
                 CaqrArgs a = caqr_args(h, k, LA[0]);
                 a.win = 2; a.pair = 1; a.tOff2 = LB[0].tOff;
+                a.xmap = xmap_tiles(LA[0].groups);
                 int rc = timed(btrail(k, nfar) + btrail(kb, nfar), h->stream, [&] { update_l0(a, LA[0], nfar, far_grid, h->stream); });
                 if (rc) return rc;
                 if (mixed) {        // problems whose J2 ends before the second panel: the first panel alone, every trailing column
@@ -1340,6 +1345,8 @@ int enlsip_gn_create(enlsip_gn_handle* out, const enlsip_gn_opts* opts) {
         const char* lk = getenv("ENLSIP_GN_LOOKAHEAD");      // 0: the pair sweep on one stream (A/B)
         if (lk && lk[0] == '0') h->lookahead = false;
         if (lk && lk[0] == '1') h->lookahead_forced = true;   // 1: for every paired sweep (tests)
+        const char* xm = getenv("ENLSIP_GN_XMAP");           // 0: native grid order for the far update of few problems with many tiles (A/B)
+        if (xm && xm[0] == '0') h->xcd_map = false;
         const char* fs = getenv("ENLSIP_GN_FUSE_SMALL");     // 0: J*Q1 and the one-tile panel factorisation as two launches (A/B)
         if (fs && fs[0] == '0') h->fuse_small = false;
         const char* fh = getenv("ENLSIP_GN_SB_FORM_HINTS");   // 0: every block of the blocked pivoted QR in all of its forms (A/B)

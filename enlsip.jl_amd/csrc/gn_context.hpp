@@ -104,6 +104,7 @@ struct enlsip_gn_context {
     bool lookahead = true;              // ENLSIP_GN_LOOKAHEAD=0: chain-bound pair sweeps on one stream
     hipStream_t stream2 = nullptr;      // second stream of the look-ahead sweep (the bulk of a pair's far update)
     std::vector<hipEvent_t> la_events;
+    bool xcd_map = true;                // ENLSIP_GN_XMAP=0: native grid order (A/B)
     bool fuse_small = true;             // ENLSIP_GN_FUSE_SMALL=0: two launches for J*Q1 + panel factorisation of one-tile problems
     int factor_nw4 = 0;                 // ENLSIP_GN_FACTOR_NW4 (A/B): 1 = level-0 tiles factored by 4 waves x 8 columns, 2 = tree nodes too
     int debug_maxpan = -1, debug_stage = -1;

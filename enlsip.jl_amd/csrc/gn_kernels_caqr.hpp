@@ -57,6 +57,8 @@ struct CaqrArgs {
     int pair;           // level-0 far update: 1 = the workgroup also applies the level-0 reflectors of panel + 1 (T blocks from
                         // tOff2) to its block of C while it sits in registers: one pass over the trailing matrix for two panels
     long long tOff2;
+    int xmap;           // level-0 far update of a pair, one problem with many tiles: > 0 = number of tiles, the grid is read
+                        // XCD-locally (gn_kernels_update_v4.hpp: k_caqr_update_v4_pair)
 };
 
 // ---------------------------------------------------------------------------------------------

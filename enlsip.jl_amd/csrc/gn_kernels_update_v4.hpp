@@ -495,14 +495,13 @@ __device__ __forceinline__ void v4_dispatch(const V4Ctx& c, int w, int ngw, doub
 // ~0.3 ms of every far-update launch of a C2 step).  T is now requested first of all (4 doubles per thread, coalesced), parked
 // in LDS with leading dimension 33 (lane k reads T[l + 33 k]: conflict-free) and the product runs fully unrolled on registers.
 template <int RPL, bool PAIR>
-__device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB], double* w2s, double* Tl) {
+__device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB], double* w2s, double* Tl, const int g) {
     constexpr int TLD = PB + 1;
     constexpr int NWV = 4;                                               // waves of the block kernel's workgroup
     const int prob = blockIdx.z + a.prob0;
     const ProbState st = a.state[prob];
     const int r0a = a.panel * PB;
     if (r0a >= st.kp) return;
-    const int g = blockIdx.x;
     const double* Wm = a.W + prob * a.sW;
     double* dcol = a.W + prob * a.sW + (size_t)a.n * a.ldw;
     const long long tile_row0 = a.base + (long long)g * a.F * 32;
@@ -610,14 +609,13 @@ __device__ __forceinline__ void v4_rhs_body(const CaqrArgs& a, double (*part)[PB
 // PAIR: the far update of a panel pair (both level-0 reflectors in one pass): only problems that HAVE the pair's second panel;
 // the plain kernel with a.pair == 2 serves the others (mixed-rank batches in the second attempt of a solve).
 template <bool TRI, bool PAIR>
-__device__ __forceinline__ bool v4_setup(const CaqrArgs& a, V4Ctx& c, int& nvu, int& ncols) {
+__device__ __forceinline__ bool v4_setup(const CaqrArgs& a, V4Ctx& c, int& nvu, int& ncols, const int g, const int yb) {
     const int prob = blockIdx.z + a.prob0;
     const ProbState st = a.state[prob];
     const int r0 = a.panel * PB;
     if (r0 >= st.kp) return false;
     c.bw = (st.kp - r0) < PB ? (st.kp - r0) : PB;
     c.col0 = st.rankA + r0;
-    const int g = blockIdx.x;
     // column window (pairs): the next panel's columns only / everything beyond them
     const int bwn = (a.win || a.pair) ? caqr_next_bw(st.kp, r0) : 0;
     if (PAIR && bwn == 0) return false;
@@ -628,7 +626,7 @@ __device__ __forceinline__ bool v4_setup(const CaqrArgs& a, V4Ctx& c, int& nvu, 
     else if (a.win == 2) { first += bwn; ncols -= bwn; }
     first += a.sub0; ncols -= a.sub0;                                    // sub-range of the window (look-ahead sweep)
     if (a.subn > 0 && ncols > a.subn) ncols = a.subn;
-    c.cb0 = blockIdx.y * ENLSIP_V4_CW;
+    c.cb0 = yb * ENLSIP_V4_CW;
     if (c.cb0 >= ncols) return false;
     c.rows_valid = 0;
     c.dshift = 32 * a.skip;
@@ -664,12 +662,12 @@ __global__ __launch_bounds__(256, ENLSIP_V4_CW == 16 ? 3 : 2) void k_caqr_update
 
     V4_STAMP(6);
     if (!TRI && a.skip_rhs && blockIdx.y == gridDim.y - 1) {             // the carried right-hand side of this tile
-        v4_rhs_body<RPL, false>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l, &stage[1][0]);
+        v4_rhs_body<RPL, false>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l, &stage[1][0], blockIdx.x);
         return;
     }
     V4Ctx c;
     int nvu, ncols;
-    if (!v4_setup<TRI, false>(a, c, nvu, ncols)) return;
+    if (!v4_setup<TRI, false>(a, c, nvu, ncols, blockIdx.x, blockIdx.y)) return;
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
     const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;                     // units w, w + 4, ... < nvu
     const bool cfull = (ncols - c.cb0 >= 32) && (c.bw == PB);
@@ -690,13 +688,28 @@ __global__ __launch_bounds__(256, 2) void k_caqr_update_v4_pair(CaqrArgs a) {
     __shared__ __attribute__((aligned(16))) double W2l[PB * PB];
 
     V4_STAMP(6);
-    if (a.skip_rhs && blockIdx.y == gridDim.y - 1) {
-        v4_rhs_body<RPL, true>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l, &stage[1][0]);
+    // Grid.  Batches: x = tile, y = column block, z = problem — the 8 tiles x ~13 column blocks of a problem are consecutive
+    // workgroups and share the tile's V out of the XCD's L2.  ONE problem with hundreds of tiles (a.xmap: C4, a 32768-row shard):
+    // in that order the 13 uses of a tile's V lie 511 workgroups = 131 MB of other tiles' V apart, every one of them a miss of the
+    // 4 MB L2.  Consecutive workgroups go to the 8 XCDs round-robin, so the launch is made 8 * ceil(tiles / 8) wide and the
+    // linear index L is read as (XCD = L mod 8, s = L / 8): the XCD runs through ITS tiles (those = XCD mod 8) with the column
+    // blocks of a tile back to back: s = tile_local * ny + column block.  A tile's V is then fetched once per pass.
+    int g = blockIdx.x, yb = blockIdx.y, ny = gridDim.y;
+    if (a.xmap) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.y;
+        const int sidx = L >> 3;
+        const int tl = sidx / ny;
+        yb = sidx - tl * ny;
+        g = 8 * tl + (L & 7);
+        if (g >= a.xmap) return;                                         // a.xmap = number of tiles; the padding of the last octet
+    }
+    if (a.skip_rhs && yb == ny - 1) {
+        v4_rhs_body<RPL, true>(a, reinterpret_cast<double (*)[PB]>(&stage[0][0]), W2l, &stage[1][0], g);
         return;
     }
     V4Ctx c;
     int nvu, ncols;
-    if (!v4_setup<false, true>(a, c, nvu, ncols)) return;
+    if (!v4_setup<false, true>(a, c, nvu, ncols, g, yb)) return;
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
     const int ngw = nvu > w ? (nvu - w + 3) / 4 : 0;
     const bool cfull = (ncols - c.cb0 >= 32) && (c.bw == PB) && (c.bw2 == PB);
@@ -710,6 +723,7 @@ inline void launch_update_v4(int RPL, const CaqrArgs& a, int groups, int ncols, 
     // level 0 with skip_rhs: ncols counts the J2 columns only; one more block index carries the right-hand side
     dim3 grid(groups, (ncols + ENLSIP_V4_CW - 1) / ENLSIP_V4_CW + ((a.level == 0 && a.skip_rhs) ? 1 : 0), batch);
     if (a.level == 0 && a.pair == 1) {
+        if (a.xmap) grid.x = 8 * ((groups + 7) / 8);                     // whole octets of tiles (see the kernel)
         if (RPL == 8) hipLaunchKernelGGL((k_caqr_update_v4_pair<8>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_caqr_update_v4_pair<4>), grid, dim3(256), 0, s, a);
     } else if (a.level == 0) {
