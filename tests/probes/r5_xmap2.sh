@@ -1,0 +1,9 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=${1:-gpurun_out/r5y}; mkdir -p $O
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py -m gpu -q --tb=short -rf -k "c2_full or shape_sweep or hints or slow_start or randomised or pipelined or batched" > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; tail -n 5 $O/pytest.log
+for i in 1 2 3; do
+  for x in 0 1; do
+    ENLSIP_GN_XMAP=$x timeout -k 10 300 python3 bench.py --cpu-budget 0 --no-live-pmc --steps 10 2> $O/c2_x${x}_$i.err | python3 tests/probes/bench_fields.py xmap $x >> $O/ab.txt
+  done
+done
+cat $O/ab.txt
