@@ -263,6 +263,31 @@ def test_extreme_magnitudes_in_a_batch_and_in_the_factored_flow(solver):
         assert rel(out.p, ref.p) <= 1e-11 and rel(np.ldexp(out.b, -eA), np.ldexp(ref.b, -eA)) <= 1e-11
 
 
+def test_extreme_magnitudes_in_both_halves_of_a_pipelined_batch(solver):
+    """130 problems = two pipelined halves on two handles: one problem of EACH half far outside the range of plain sums
+    of squares.  Each half hands its problem to a rescue handle of its own; outputs in the caller's slots, accessors routed through
+    the half to the rescue handle (need_factors)."""
+    from enlsip_gn import FACTOR_J2
+    m, n, t, B = 300, 66, 5, 130
+    probs = [list(synth.make_problem(63000 + k, m, n, t)) for k in range(B)]
+    for k, e in ((3, 700), (100, -650)):
+        probs[k][0], probs[k][1] = np.ldexp(probs[k][0], e), np.ldexp(probs[k][1], e)
+    probs[101][2], probs[101][3] = np.ldexp(probs[101][2], 600), np.ldexp(probs[101][3], 600)
+    p, b, d, infos, jA, jL, jJ = solver.solve_batched(np.stack([np.ascontiguousarray(P[0].T) for P in probs]), np.stack([P[1] for P in probs]),
+                                                      np.stack([np.ascontiguousarray(P[2]) for P in probs]), np.stack([P[3] for P in probs]))
+    assert solver.pipeline_split() == 65 and "rescaled" in solver.route()
+    for k in (0, 3, 4, 64, 65, 100, 101, 102, 129):
+        ref = go.gn_subproblem(*probs[k])
+        assert (infos[k][0], infos[k][1], infos[k][2], infos[k][5]) == (ref.rankA, ref.rankJ2, ref.code, 0), k
+        assert rel(p[k], ref.p) <= 1e-11, (k, rel(p[k], ref.p))
+        r = ref.rankJ2
+        assert np.array_equal(jJ[k][:r], ref.jpvtJ2[:r]), k
+        if r:
+            fv = solver.factor(FACTOR_J2, prob=k)
+            dg, dgr = np.abs(fv.diagR()[:r]), np.abs(ref.F_J2.diagR()[:r])
+            assert np.abs(dg / dgr - 1.0).max() <= 1e-10, k
+
+
 @pytest.mark.parametrize("m,n,t", [(700, 48, 6), (900, 200, 70), (512, 256, 64), (300, 40, 0)])
 def test_matrix_times_QA_and_the_full_constraint_product(m, n, t, solver):
     """`M * F_A.Q` for ANY matrix with the row count of the last solve (what the Julia glue's `*(::AbstractMatrix, ::DeviceQ)`

@@ -414,11 +414,11 @@ def test_two_problem_waves_with_more_than_64_constraint_reflectors(m, n, t, batc
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("probe,count,seed", [("fuzz_batched", 25, 62), ("fuzz_batched", 25, 5), ("fuzz_batched", 25, 19),
-                                              ("fuzz_gpu", 100, 71), ("fuzz_gpu", 100, 3), ("fuzz_gpu", 100, 29),
-                                              ("fuzz_accessors", 30, 1), ("fuzz_accessors", 30, 2), ("fuzz_accessors", 30, 3),
-                                              ("fuzz_tsqr", 6, 1), ("fuzz_tsqr", 6, 2), ("fuzz_tsqr", 6, 3),
-                                              ("fuzz_magnitudes", 40, 1), ("fuzz_magnitudes", 40, 2), ("fuzz_magnitudes", 40, 3)])
+@pytest.mark.parametrize("probe,count,seed", [("fuzz_batched", 16, 62), ("fuzz_batched", 16, 5), ("fuzz_batched", 16, 19),
+                                              ("fuzz_gpu", 70, 71), ("fuzz_gpu", 70, 3), ("fuzz_gpu", 70, 29),
+                                              ("fuzz_accessors", 20, 1), ("fuzz_accessors", 20, 2), ("fuzz_accessors", 20, 3),
+                                              ("fuzz_tsqr", 5, 1), ("fuzz_tsqr", 5, 2), ("fuzz_tsqr", 5, 3),
+                                              ("fuzz_magnitudes", 30, 1), ("fuzz_magnitudes", 30, 2), ("fuzz_magnitudes", 30, 3)])
 def test_randomised_shapes_against_the_oracle(probe, count, seed, monkeypatch):
     """The randomised sweeps of tests/probes (mixed batches: full rank, rank-deficient A / J2, graded J2, zero A; single problems of
     every size class; the accessors and the re-solve on random shapes; row-sharded TSQR solves; random shapes at random power-of-two
