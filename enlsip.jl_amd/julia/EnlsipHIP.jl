@@ -326,6 +326,29 @@ function full_constraints_times_hip(h::Handle, A::Matrix{Float64}, p::Vector{Flo
     return Ap
 end
 
+"""    route(h) -> Vector{String}: the kernel-selection branches the last solve on `h` took (enlsip_gn_get_route; diagnostics)"""
+function route(h::Handle)
+    mask = Ref{UInt64}(0)
+    check(h, ccall((:enlsip_gn_get_route, LIB), Cint, (Ptr{Cvoid}, Ref{UInt64}), h.ptr, mask))
+    names = String[]
+    bit = 0
+    while true
+        nm = ccall((:enlsip_gn_route_name, LIB), Cstring, (Cint,), bit)
+        nm == C_NULL && break
+        (mask[] >> bit) & 1 == 1 && push!(names, unsafe_string(nm))
+        bit += 1
+    end
+    return names
+end
+
+"""    tsqr_exchange(h) -> (transport, ranks, rank_tags_seen) of the last `gn_search_direction_tsqr_hip` on `h`:
+`rank_tags_seen == ranks` on every rank means one correctly tagged message from each rank arrived (transport 1 = RCCL)."""
+function tsqr_exchange(h::Handle)
+    tr = Ref{Cint}(-1); rk = Ref{Cint}(0); seen = Ref{Cint}(-1)
+    check(h, ccall((:enlsip_gn_tsqr_get_exchange, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cint}), h.ptr, tr, rk, seen))
+    return Int(tr[]), Int(rk[]), Int(seen[])
+end
+
 """    diagR(F::DeviceQR) -> diag(F.R) without moving the triangle (what `pseudo_rank(diag(F.R), ε)` needs, :768, :224)"""
 function diagR(F::DeviceQR)
     r, c = factor_shape(F)

@@ -28,6 +28,16 @@ def test_header_symbols_exported(lib):
     assert lib.enlsip_gn_version() >= 100
 
 
+def test_route_names_match_the_header(lib):
+    """enlsip_gn_route_name (no GPU needed) speaks the header's ENLSIP_GN_ROUTE_* vocabulary, bit for bit — the vocabulary the
+    dispatch-derived shape grid is written in (tests/dispatch_grid.py)."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tests"))
+    import dispatch_grid as dg
+    from enlsip_gn.api import route_names
+    assert route_names(lib) == dg.header_route_names()
+
+
 def test_header_cites_reference_lines():
     hdr = (ROOT / "include" / "enlsip_gn.h").read_text()
     for cite in ("src/enlsip_functions.jl:206-234", "src/enlsip_functions.jl:116-153",
