@@ -37,6 +37,13 @@
  *   - "_dev" entry points take DEVICE pointers (hipMalloc memory on the handle's device) and
  *     leave results in device memory; the others take HOST pointers and stage through PCIe.
  *   - Factors stay resident on the device behind the handle until the next solve on it.
+ *   - Magnitudes.  qr(., ColumnNorm()) of the reference is dgeqp3, whose norms and reflectors scale internally: inputs of any
+ *     magnitude are factored alike and pseudo_rank's absolute first test (src/enlsip_functions.jl:19) decides the rank.  The
+ *     kernels square plainly; enlsip_gn_solve*, _solve_batched*, _factor_constraints and _solve_factored therefore detect inputs
+ *     whose entries leave the range of plain sums of squares (beyond about 2^+-500) on their result and solve them again on
+ *     copies scaled by a power of two, with the resident factors and the outputs scaled back: ranks, pivots,
+ *     p, b, d and every accessor are those of the caller's data, as LAPACK would return them.  NOT covered: the row shards of the
+ *     TSQR entry points (all shards of one matrix would have to agree on one scale before their local stages).
  */
 #ifndef ENLSIP_GN_H
 #define ENLSIP_GN_H
