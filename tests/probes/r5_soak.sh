@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/r5soak}; mkdir -p $O
 run() { name=$1; shift; timeout -k 10 300 python3 "$@" > $O/$name.log 2>&1; echo "$name rc $? : $(tail -n 1 $O/$name.log)"; }
-for s in 11 12 13 14; do
+for s in ${SEEDS:-11 12 13 14}; do
   run fuzz_magnitudes_$s tests/probes/fuzz_magnitudes.py 200 $((1000 + s))
   run fuzz_gpu_$s tests/probes/fuzz_gpu.py 300 $((2000 + s))
   run fuzz_batched_$s tests/probes/fuzz_batched.py 60 $((3000 + s))
