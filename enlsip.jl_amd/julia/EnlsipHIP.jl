@@ -110,7 +110,6 @@ Base.adjoint(Q::DeviceQ) = DeviceQ(Q.F, !Q.adj)
 
 function Base.:*(Q::DeviceQ, v::AbstractVector{Float64})
     out = Vector{Float64}(v)
-    f = Q.adj ? :enlsip_gn_apply_qt : :enlsip_gn_apply_q
     h = getfield(Q.F, :h)
     GC.@preserve out begin
         rc = Q.adj ?
@@ -333,7 +332,7 @@ function route(h::Handle)
     names = String[]
     bit = 0
     while true
-        nm = ccall((:enlsip_gn_route_name, LIB), Cstring, (Cint,), bit)
+        nm = ccall((:enlsip_gn_route_name, LIB), Ptr{UInt8}, (Cint,), bit)
         nm == C_NULL && break
         (mask[] >> bit) & 1 == 1 && push!(names, unsafe_string(nm))
         bit += 1
