@@ -269,14 +269,24 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
     }
     __syncthreads();
     FACTOR_STAMP(2);
-    // store the tile back (V below / R on and above the diagonal; tree levels: upper triangles)
+    // store the tile back (V below / R on and above the diagonal; tree levels: upper triangles).  The lane's slot geometry is formed
+    // AGAIN here, from an opaque copy of the lane index: kept from the load phase, the 64-bit lane offset and the row masks stayed
+    // live across the step loop — 27 of the 126 registers of the 8-wave form (now 99; the 4-wave forms 207 -> 171 and 124 -> 101).
+    {
+        int lns = ln;
+        asm volatile("" : "+v"(lns));
+        const int rbs = lns & 31, qhs = lns >> 5;
+        const bool dnss = split && qhs == 1;
+        const long long lane_off_s = split ? (qhs ? a.S : 32) + rbs : (long long)qhs * a.S + rbs;
 #pragma unroll
-    for (int cc = 0; cc < NC; ++cc) {
-        const int c = w + NW * cc;
+        for (int cc = 0; cc < NC; ++cc) {
+            const int c = w + NW * cc;
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            const bool ok = (c < bwp) && bval(i) && (!tri || dns || (c < bw ? rb <= c : rb < bw));
-            if (ok) W[ubase(c, i) + lane_off] = x[cc][i];
+            for (int i = 0; i < RPL; ++i) {
+                const bool in = (long long)g * a.F + qhs + 2 * i < a.nblocks && qhs + 2 * i >= a.skip;
+                const bool ok = (c < bwp) && in && (!tri || dnss || (c < bw ? rbs <= c : rbs < bw));
+                if (ok) W[ubase(c, i) + lane_off_s] = x[cc][i];
+            }
         }
     }
     FACTOR_STAMP(3);
@@ -284,7 +294,11 @@ __device__ __forceinline__ void caqr_factor_core(const CaqrArgs& a, const int pr
     if (!GRAM) {
         if (w == 0) {                // diag(T) = tau, zeros elsewhere (lane r + 32 hh writes every second entry of row r)
             double* T = a.Tbuf + prob * a.sT + (a.tOff + g) * (long long)(PB * PB);
-            const int r = ln & 31, hh = ln >> 5;
+            // from an opaque copy of the lane index: `ln & 31` is also what the fused small kernel's staging computes at its very
+            // start, and as one common value it lived across the step loop in a spill slot, reloaded in every step
+            int lnt = ln;
+            asm volatile("" : "+v"(lnt));
+            const int r = lnt & 31, hh = lnt >> 5;
             const double tr = taush[r];
 #pragma unroll
             for (int j2 = 0; j2 < PB / 2; ++j2) {
