@@ -230,7 +230,7 @@ constexpr long long GN_MAX_LAUNCH_BATCH = 32768;
 static int check_limits(enlsip_gn_handle h, long long batch, long long m, long long n, long long t) {
     if (batch < 1) { h->err = "batch must be >= 1"; return -2; }
     if (batch > (1LL << 31) - 1) { h->err = "batch must be < 2^31"; return -2; }
-    if (m < 1 || m > (1LL << 27)) { h->err = "m out of range (1 .. 2^27: 32-bit lane offsets in the update kernel)"; return -3; }
+    if (m < 1 || m > (1LL << 27) - 4096) { h->err = "m out of range (1 .. 2^27 - 4096: 32-bit lane offsets in the update kernels)"; return -3; }
     if (n < 1 || n > 1024) { h->err = "n must be in 1..1024 in this build"; return -4; }
     if (t < 0 || t > 1024) { h->err = "t must be in 0..1024 in this build"; return -5; }
     return 0;

@@ -81,6 +81,9 @@ __device__ int g_v4_stamp_x = 3;      // group index (blockIdx.x) of the sampled
 #ifndef ENLSIP_V4_IMM_UNIT
 #define ENLSIP_V4_IMM_UNIT 1
 #endif
+#ifndef ENLSIP_V4_TRI_UNIT_VOFF
+#define ENLSIP_V4_TRI_UNIT_VOFF 1
+#endif
 #ifndef ENLSIP_V4_START_FENCE
 #define ENLSIP_V4_START_FENCE 1
 #endif
@@ -152,11 +155,26 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
     // serves every unit and 1024 g bytes ride in the immediate offset of the access: 8 + 8 per block reflector scalar bases
     // instead of one per (unit, column) — those did not fit the scalar file (1200 scalar spills into vector lanes, the reloads
     // in the middle of the MFMA chains).
+    // Tree levels: the units of a wave are S rows apart (not a compile-time distance), and one uniform base per (unit, column) —
+    // 64 of them for C and V — overflowed the scalar file: the tree kernel carried 158 scalar spills into vector lanes and ~1000
+    // v_readlane reloads, 46 k instructions against 33 k for the pair kernel that does twice the work.  The unit's distance from the
+    // wave's unit 0 now rides in the per-lane offset (ONE more 32-bit register per unit): 8 + 8 uniform bases as at level 0.
+    // (m <= 2^27 - 4096, check_limits: lane offset + unit distance < 2^32 bytes.)
+    const long long row00 = rowu(0);                                                           // uniform
+    unsigned uoff[NGW > 0 ? NGW : 1];
+    if (TRI && !GATHER && ENLSIP_V4_TRI_UNIT_VOFF) {
+#pragma unroll
+        for (int g = 0; g < NGW; ++g) uoff[g] = lane_byte + (unsigned)((rowu(g) - row00) * (long long)sizeof(double));
+    }
     auto cptr = [&](int g, int ct, int r) -> double* {
         if (GATHER) return (double*)((char*)(c.C + rowu(g)) + (coff[4 * ct + r] + 16u * (unsigned)lr));
         if (!TRI && ENLSIP_V4_IMM_UNIT) {
             double* ub = c.C + (size_t)(c.cb0 + 16 * ct + 4 * r) * c.ldw + (c.tile_row0 + 32 * w);      // uniform
             return (double*)((char*)ub + lane_byte) + 128 * g;
+        }
+        if (TRI && ENLSIP_V4_TRI_UNIT_VOFF) {
+            double* ub = c.C + (size_t)(c.cb0 + 16 * ct + 4 * r) * c.ldw + row00;     // uniform, the same for every unit
+            return (double*)((char*)ub + uoff[g]);
         }
         double* ub = c.C + (size_t)(c.cb0 + 16 * ct + 4 * r) * c.ldw + rowu(g);      // uniform
         return (double*)((char*)ub + lane_byte);
@@ -165,6 +183,10 @@ __device__ __forceinline__ void v4_body(const V4Ctx& c, const int w, double (*st
         if (!TRI && ENLSIP_V4_IMM_UNIT) {
             const double* ub = c.Wm + (size_t)(ap_col0(ai) + 4 * ks) * c.ldw + (c.tile_row0 + 32 * w);      // uniform
             return (const double*)((const char*)ub + lane_byte) + 128 * g;
+        }
+        if (TRI && !GATHER && ENLSIP_V4_TRI_UNIT_VOFF) {
+            const double* ub = c.Wm + (size_t)(ap_col0(ai) + 4 * ks) * c.ldw + row00;      // uniform, the same for every unit
+            return (const double*)((const char*)ub + uoff[g]);
         }
         const double* ub = c.Wm + (size_t)(ap_col0(ai) + 4 * ks) * c.ldw + rowu(g);       // uniform
         return (const double*)((const char*)ub + lane_byte);
