@@ -83,14 +83,32 @@ __global__ __launch_bounds__(256, 4) void k_jq1_factor_small(JQ1Args q, CaqrArgs
     }
     rxv = live ? rxv : 0.0;
     __syncthreads();
+    // A reflector is read from LDS in HALVES, once for the dot product and once for the update (broadcast reads: every lane the same
+    // address).  Read whole and kept, its 32 values (64 registers) beside the 64 of the row pushed two quads of the row into spill
+    // slots inside this loop — two scratch round trips per reflector, each behind a vmcnt(0) (tests/probes/isa_scratch_in_loops.py).
+    constexpr int NH = NMAX / 2;
     for (int k = 0; k < kA; ++k) {
         const double* vk = Vs + k * NMAX;
         double dot = 0.0;
 #pragma unroll
-        for (int c = 0; c < NMAX; ++c) dot += xr[c] * vk[c];
+        for (int h = 0; h < 2; ++h) {
+            double vv[NH];
+#pragma unroll
+            for (int c = 0; c < NH; ++c) vv[c] = vk[NH * h + c];
+#pragma unroll
+            for (int c = 0; c < NH; ++c) dot += xr[NH * h + c] * vv[c];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const double s = taus[k] * dot;
 #pragma unroll
-        for (int c = 0; c < NMAX; ++c) xr[c] -= s * vk[c];
+        for (int h = 0; h < 2; ++h) {
+            double vv[NH];
+#pragma unroll
+            for (int c = 0; c < NH; ++c) vv[c] = vk[NH * h + c];
+#pragma unroll
+            for (int c = 0; c < NH; ++c) xr[NH * h + c] -= s * vv[c];
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     double ds = 0.0;
 #pragma unroll
